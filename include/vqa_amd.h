@@ -1,0 +1,258 @@
+/*
+ * vqa_amd.h - C ABI of libvqa_amd.so, the MI355X (gfx950) module executor.
+ *
+ * The reference (Jacobjohansen90/VQA) has no FFI: its executor is the Python class ModuleNet
+ * (Module_Model.py:95-248) calling torch.nn ops.  This library is what a binding for that hot
+ * path binds instead; every entry point names the reference lines it replaces.  The Python host
+ * (vqa_amd/module_net.py) loads it with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers are raw HIP device addresses
+ *   - the caller owns every device buffer, workspaces included; nothing here allocates device
+ *     memory (the scheduler allocates host memory for its plan)
+ *   - device entry points enqueue work on `stream` and return without waiting
+ *   - return 0 on success, nonzero VQA_E* otherwise; vqa_last_error() gives the message of the
+ *     calling thread's last failure
+ *   - activations are bf16, channels-last: a feature map is [196 pixels][C channels]; a "slot"
+ *     is one such map inside the arena; C is a multiple of 128; the image is 14 x 14
+ */
+#ifndef VQA_AMD_H
+#define VQA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQA_OK 0
+#define VQA_EINVAL 1   /* bad argument (shape, alignment, null pointer) */
+#define VQA_ELAUNCH 2  /* HIP reported an error at launch */
+#define VQA_EVOCAB 3   /* program token id outside the vocabulary (the reference raises KeyError) */
+
+#define VQA_HW 196     /* 14 x 14 pixels per feature map */
+
+int vqa_version(void);
+const char* vqa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Program scheduler (host).  Replaces the per-sample recursive interpreter
+ * forward_modules_ints_helper / forward_modules_ints (Module_Model.py:196-233): parses every
+ * prefix program row with the reference's exact rules, then buckets the tree nodes of the whole
+ * batch by (tree level, token) so that each level runs as a few grouped launches.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vqa_plan vqa_plan;
+
+typedef struct {
+    int32_t N, T, C;
+    int32_t num_nodes, num_scene, num_unary, num_binary; /* scene incl. implicit; unary incl. specials */
+    int32_t num_levels;
+    int32_t slots_fwd;      /* arena slots needed for forward only */
+    int32_t slots_total;    /* forward + backward */
+    int32_t blob_words;     /* int32 words of the device descriptor blob */
+    int32_t wgrad_items;    /* work items of the grouped weight-gradient launch */
+    int32_t max_level_tiles;
+    int32_t reserved[3];
+} vqa_plan_info;
+
+/* programs: host int64 [N][T].  arity: int8 [V] (0 scene, 1 unary, 2 binary), indexed by token id
+ * (Program_funcs.py:114-122).  null_id / start_id: ids of <NULL> and <START> (Functions.py:44-45).
+ * scene_id: id of 'scene'.  C: module width.  wgrad_chunk: nodes per weight-gradient work item. */
+int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T, const int8_t* arity,
+                       int32_t V, int32_t null_id, int32_t start_id, int32_t scene_id, int32_t C,
+                       int32_t wgrad_chunk, vqa_plan** out);
+void vqa_plan_free(vqa_plan* plan);
+int vqa_plan_get_info(const vqa_plan* plan, vqa_plan_info* out);
+/* used_fns as ModuleNet.used_fns (Module_Model.py:227,231): float [N][T] of 0/1 */
+int vqa_plan_used_fns(const vqa_plan* plan, float* out);
+/* node table, execution (post-)order per sample, samples in order: int32 [num_nodes][6] =
+ * {sample, token, column (-1 implicit scene), child0, child1 (global node ids, -1 none), level} */
+int vqa_plan_nodes(const vqa_plan* plan, int32_t* out);
+/* nodes of a level in launch order (sorted by token, then node id); returns count */
+int vqa_plan_level_nodes(const vqa_plan* plan, int32_t level, int32_t* out, int32_t cap);
+/* per-token node counts: int32 [V] */
+int vqa_plan_token_counts(const vqa_plan* plan, int32_t* out);
+/* root node id of each sample: int32 [N] */
+int vqa_plan_roots(const vqa_plan* plan, int32_t* out);
+/* the descriptor blob to copy to the device before running the tree (blob_words int32) */
+int vqa_plan_blob(const vqa_plan* plan, int32_t* out);
+/* Sections of the blob that the host needs by name (the per-level tile lists are used by
+ * vqa_tree_forward / vqa_tree_backward internally).  offset is in int32 words. */
+enum {
+    VQA_SEC_STEM0_TILES = 0,   /* conv tiles: x[sample] -> S0(sample) */
+    VQA_SEC_STEM1_TILES,       /* S0 -> F */
+    VQA_SEC_STEM1_DGRAD_TILES, /* dF -> dS0, mask S0 */
+    VQA_SEC_CLS_FWD_TILES,     /* Y(root of sample) -> row `sample` of the classifier input: the
+                                  torch.cat of Module_Model.py:232 becomes a gather */
+    VQA_SEC_CLS_DGRAD_TILES,   /* row `sample` -> dZ(root), mask Y(root) */
+    VQA_SEC_SLOTS_IDENT,       /* 0..N-1 */
+    VQA_SEC_SLOTS_S0, VQA_SEC_SLOTS_F, VQA_SEC_SLOTS_DF, VQA_SEC_SLOTS_DS0, VQA_SEC_SLOTS_ROOTY,
+    VQA_SEC_SAMPLE_ITEMS,      /* vqa_wgrad_item list cutting 0..N-1 into chunks, group 0 */
+    VQA_SEC_SCENE_OFFSETS, VQA_SEC_SCENE_SRC,
+    VQA_SEC_WG_ITEMS, VQA_SEC_WG_SRC_C1, VQA_SEC_WG_DY_C1, VQA_SEC_WG_SRC_C2, VQA_SEC_WG_DY_C2,
+    VQA_SEC_WG_PITEMS, VQA_SEC_WG_PSRC0, VQA_SEC_WG_PSRC1, VQA_SEC_WG_PDY,
+    VQA_SEC_COUNT
+};
+int vqa_plan_section(const vqa_plan* plan, int32_t id, int32_t* offset, int32_t* count);
+/* arena slot ids: which = 0 F(sample) 1 S0(sample) 2 Y(node) 3 H(node)
+ * 4 dZ(node) 5 dH(node) 6 dF(sample) 7 dS0(sample); returns slot or -1 */
+int32_t vqa_plan_slot(const vqa_plan* plan, int32_t which, int32_t index);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped convolution over tiles.  One tile = one 14x14 feature map x 128 output channels.
+ * Replaces every batch-1 nn.Conv2d call of the interpreter (Layers.py:33-36,
+ * Module_Model.py:38-40,47-50), the batched stem convs (Module_Model.py:59-62) and the classifier
+ * 1x1 conv (:72-75), and, with flipped weights, their input gradients.
+ *   out = epilogue( sum_{chunk, tap} W[group][chunk][tap] * src[chunk](pixel + tap) )
+ * epilogue: + bias[group], + res, ReLU, or multiply by (mask > 0), by flags / per-tile slots.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t src0, src1;   /* source slots */
+    int32_t dst0, dst1;   /* destination slots */
+    int32_t res;          /* residual slot or -1 */
+    int32_t mask0, mask1; /* mask slots or -1 */
+    int32_t wgroup;       /* weight group (token id) */
+} vqa_conv_tile;
+
+#define VQA_CONV_BIAS 1
+#define VQA_CONV_RELU 2
+
+typedef struct {
+    const void* src;        /* bf16 base of source slots */
+    void* dst;              /* bf16 base of destination slots */
+    const void* res;        /* bf16 base of residual slots (geometry of dst) */
+    const void* mask;       /* bf16 base of mask slots (geometry of dst) */
+    const void* w;          /* packed bf16 weights, see vqa_pack_conv_weight */
+    const float* bias;      /* fp32 [groups][n_out] or null */
+    const vqa_conv_tile* tiles; /* device */
+    int64_t src_slot_stride;/* elements between source slots */
+    int64_t dst_slot_stride;
+    int64_t w_group_stride; /* elements between weight groups */
+    int32_t src_pix_stride; /* elements between pixels of a source map */
+    int32_t dst_pix_stride;
+    int32_t k_chunks;       /* 128-channel source chunks; K = k_chunks * taps * 128 */
+    int32_t n_out;          /* output channels, multiple of 128 */
+    int32_t pair_chunks;    /* 0: chunk c is channels [128c,128c+128) of src0.  >0: chunk c is
+                               channels [128(c%pair),..) of (c/pair ? src1 : src0) */
+    int32_t pair_out;       /* same rule for the 128-wide output tiles and dst0/dst1, mask0/mask1 */
+    int32_t flags;
+    int32_t num_tiles;
+} vqa_conv_params;
+
+int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps /* 9 or 1 */, void* stream);
+
+/* Weight packing: fp32 tensor -> bf16 image the conv kernel DMA-copies into LDS.
+ * Source element (n, k, t) is at w[group*g_stride + n*n_stride + k*k_stride + (flip ? taps-1-t : t)]
+ * (forward: n = out channel, k = in channel; input-gradient: swapped and flipped). */
+int vqa_pack_conv_weight(const float* w, void* packed, int32_t groups, int32_t n_out, int32_t k_in,
+                         int32_t taps, int64_t g_stride, int64_t n_stride, int64_t k_stride,
+                         int32_t flip, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped weight gradient: dW[group][tap][i][o] += sum over the group's nodes and pixels of
+ * src(pixel + tap)[i] * dy(pixel)[o]; db[group][o] += sum dy(pixel)[o].  Replaces autograd's
+ * per-call conv weight gradients and their accumulation into the shared per-token weights
+ * (Train_model.py:313 over Module_Model.py:221).  fp32 atomic accumulation.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t group;   /* weight group (token id) */
+    int32_t first;   /* first entry of src_slots / dy_slots */
+    int32_t count;   /* nodes in this item */
+    int32_t pad;
+} vqa_wgrad_item;
+
+typedef struct {
+    const void* src;            /* bf16 base of source slots */
+    const void* dy;             /* bf16 base of gradient slots */
+    const vqa_wgrad_item* items;/* device */
+    const int32_t* src_slots;   /* device: per node, source slot (pair: src1_slots too) */
+    const int32_t* src1_slots;  /* device or null */
+    const int32_t* dy_slots;    /* device */
+    float* dw;                  /* fp32 [groups][taps][k_in][n_out] accumulators */
+    float* db;                  /* fp32 [groups][n_out] or null */
+    int64_t src_slot_stride, dy_slot_stride;
+    int64_t dw_group_stride;    /* elements */
+    int32_t src_pix_stride, dy_pix_stride;
+    int32_t k_chunks;           /* 128-channel chunks of the source (i) dimension */
+    int32_t pair_chunks;        /* as in vqa_conv_params */
+    int32_t n_out;              /* channels of dy (o), multiple of 64 */
+    int32_t num_items;
+} vqa_wgrad_params;
+
+int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* stream);
+
+/* dW accumulators [groups][taps][k][n] fp32 -> torch layout [n][k][taps] (OIHW), groups apart by
+ * out_g_stride */
+int vqa_unpack_conv_grad(const float* dw, float* out, int32_t groups, int32_t n_out, int32_t k_in,
+                         int32_t taps, int64_t out_g_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense GEMM for the classifier's linear layers (Module_Model.py:85-92) and their gradients.
+ * C[M][N] (+)= A * B with bf16 operands; a_kmajor = 0: A is [M][K] (lda = row stride), 1: A is
+ * stored [K][M]; b_kmajor = 0: B is stored [N][K] (weights [out][in]), 1: B is stored [K][N].
+ * Operand buffers must be allocated (and zero filled) out to multiples of 128 rows/cols and K must
+ * be a multiple of 64.  out_mode 1: fp32 store; with split_k > 1 slab z (the partial sum over its
+ * share of K) goes to c + z*M*ldc and the caller adds the slabs (vqa_bias_act does);
+ * out_mode 2: bf16 store, times (mask > 0) when mask is non-null (mask has C's geometry, bf16).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* a; const void* b; void* c; const void* mask;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, K;
+    int32_t a_kmajor, b_kmajor, out_mode, split_k;
+} vqa_gemm_params;
+
+int vqa_gemm(const vqa_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout and elementwise helpers
+ * ------------------------------------------------------------------------------------------ */
+/* x fp32 [N][Cin][196] (NCHW, the loader's layout, Train_model.py:311) -> bf16 [N][196][Cpad] */
+int vqa_nchw_to_nhwc(const float* x, void* out, int32_t N, int32_t Cin, int32_t Cpad, void* stream);
+/* bf16 [N][196][C] -> fp32 [N][C][196] */
+int vqa_nhwc_to_nchw(const void* x, float* out, int32_t N, int32_t C, void* stream);
+/* fp32 [rows][cols] -> bf16 [rows_pad][cols_pad] (zero padded) */
+int vqa_cast_pad(const float* w, void* out, int32_t rows, int32_t cols, int32_t rows_pad,
+                 int32_t cols_pad, void* stream);
+/* FC weight over the flattened [P][196] map (Layers.py:42-44 flatten order c*196+hw) <-> the
+ * channels-last order hw*P+c.  to_nhwc: fp32 [F][P*196] -> bf16 [Fpad][196*P];
+ * from_nhwc: fp32 [F][196*P] -> fp32 [F][P*196] */
+int vqa_fc_weight_to_nhwc(const float* w, void* out, int32_t F, int32_t Fpad, int32_t P, void* stream);
+int vqa_fc_grad_from_nhwc(const float* g, float* out, int32_t F, int32_t P, void* stream);
+/* out[rows][ld_out] = act(sum over `slabs` split-K slabs of acc fp32 [rows][ld_acc] + bias[col]) for
+ * col < cols; out is bf16, or fp32 when out_f32 */
+int vqa_bias_act(const float* acc, const float* bias, void* out, int32_t rows, int32_t cols,
+                 int64_t ld_acc, int64_t ld_out, int32_t relu, int32_t slabs, int64_t slab_stride,
+                 int32_t out_f32, void* stream);
+/* out[col] += sum over rows of x[row][col]; x bf16 (is_bf16) or fp32 */
+int vqa_col_sum(const void* x, float* out, int32_t rows, int32_t cols, int64_t ld, int32_t is_bf16,
+                void* stream);
+/* dst slot <- (sum of listed source slots) * (mask slot > 0): scene-node gradient fan-in
+ * (feats[i:i+1] is read by every scene node of sample i, Module_Model.py:214) */
+int vqa_slot_sum_mask(void* arena, const int32_t* offsets, const int32_t* src_slots,
+                      const int32_t* dst_slots, const int32_t* mask_slots, int32_t n_dst,
+                      int64_t slot_elems, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole module tree.  Replaces forward_modules_ints (Module_Model.py:224-233) and autograd's
+ * backward over it.  `blob` is the device copy of vqa_plan_blob.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    void* arena;                       /* bf16 [slots][196][C] */
+    const int32_t* blob;               /* device */
+    const void *w_conv1, *w_conv2, *w_proj;     /* packed forward weights, one group per token */
+    const void *wd_conv1, *wd_conv2, *wd_proj;  /* packed input-gradient weights */
+    const float *b_conv1, *b_conv2, *b_proj;    /* fp32 [V][C] */
+    float *g_conv1, *g_conv2, *g_proj;          /* fp32 accumulators [V][9][C][C], [V][2C][C] */
+    float *gb_conv1, *gb_conv2, *gb_proj;       /* fp32 [V][C] */
+    int32_t C, V;
+} vqa_tree_ctx;
+
+int vqa_tree_forward(const vqa_plan* plan, const vqa_tree_ctx* ctx, void* stream);
+/* input gradients level by level, scene fan-in, then all weight gradients */
+int vqa_tree_backward(const vqa_plan* plan, const vqa_tree_ctx* ctx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,129 @@
+"""The native scheduler (host code in libvqa_amd.so) against the oracle's restatement of the
+reference interpreter, bit-exact: node order, tokens, children, columns, used_fns, level buckets."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.module_net_ref import parse_row
+from vqa_amd import synth
+from vqa_amd.schedule import Plan
+
+
+def oracle_nodes(prog, vocab):
+    """Global node table the way the scheduler numbers it, from the oracle's per-row parse."""
+    i2t, t2i = vocab['program_idx_to_token'], vocab['program_token_to_idx']
+    rows, used, roots = [], [], []
+    for i in range(prog.shape[0]):
+        nodes, u = parse_row(prog[i].tolist(), i2t)
+        base = len(rows)
+        lev = []
+        for tok, col, kids in nodes:
+            lv = 0 if not kids else 1 + max(lev[k] for k in kids)
+            lev.append(lv)
+            k = [base + c for c in kids] + [-1, -1]
+            rows.append([i, t2i[tok], col, k[0], k[1], lv])
+        roots.append(len(rows) - 1)
+        used.append(u)
+    return np.array(rows, dtype=np.int32), np.array(used, dtype=np.float32), np.array(roots, dtype=np.int32)
+
+
+def check_against_oracle(prog, vocab):
+    plan = Plan(prog, vocab)
+    nodes, used, roots = oracle_nodes(prog, vocab)
+    np.testing.assert_array_equal(plan.nodes(), nodes)
+    np.testing.assert_array_equal(plan.used_fns(), used)
+    np.testing.assert_array_equal(plan.roots(), roots)
+    assert plan.info.num_nodes == len(nodes)
+    assert plan.info.num_levels == nodes[:, 5].max() + 1
+    seen = []
+    for L in range(plan.info.num_levels):
+        lv = plan.level_nodes(L)
+        want = sorted(np.nonzero(nodes[:, 5] == L)[0].tolist(), key=lambda v: (nodes[v, 1], v))
+        assert lv.tolist() == want
+        seen += lv.tolist()
+    assert sorted(seen) == list(range(len(nodes)))
+    np.testing.assert_array_equal(plan.token_counts(), np.bincount(nodes[:, 1], minlength=len(vocab['program_token_to_idx'])))
+    scene = vocab['program_token_to_idx']['scene']
+    assert plan.info.num_scene == int((nodes[:, 1] == scene).sum())
+    assert plan.info.num_binary == int((nodes[:, 4] >= 0).sum())
+    assert plan.info.num_unary == len(nodes) - plan.info.num_scene - plan.info.num_binary
+    return plan, nodes
+
+
+def test_quirk_rows_match_reference_trace(vocab, golden_dir):
+    """Directly against the hook trace captured from the reference executor."""
+    with open(os.path.join(golden_dir, 'schedule_quirks.json')) as f:
+        cases = json.load(f)['cases']
+    scene = vocab['program_token_to_idx']['scene']
+    for c in cases:
+        plan = Plan(np.array([c['program']], dtype=np.int64), vocab)
+        nd = plan.nodes()
+        assert nd[:, 1].tolist() == c['tokens'], c['name']
+        kids = [[-1] if t == scene else [k for k in (a, b) if k >= 0] for t, a, b in nd[:, [1, 3, 4]].tolist()]
+        assert kids == c['children'], c['name']
+        assert plan.used_fns()[0].astype(int).tolist() == c['used_fns'], c['name']
+
+
+def test_wellformed_batch(vocab):
+    check_against_oracle(synth.synth_programs(1, 257, vocab), vocab)
+
+
+def test_sampler_batch_ragged_T(vocab):
+    check_against_oracle(synth.synth_sampler_programs(2, 300, 44, 30), vocab)
+    check_against_oracle(synth.synth_sampler_programs(3, 64, 44, 7), vocab)
+    check_against_oracle(synth.synth_programs(4, 32, vocab, max_len=64, max_nodes=60), vocab)
+    check_against_oracle(synth.synth_programs(5, 16, vocab, with_start=True), vocab)
+
+
+def test_worst_case_sizes(vocab):
+    t2i = vocab['program_token_to_idx']
+    T = 30
+    prog = np.array([[t2i['union']] * T, [0] * T, [t2i['scene']] + [0] * (T - 1)], dtype=np.int64)
+    plan, nodes = check_against_oracle(prog, vocab)
+    assert (nodes[:, 0] == 0).sum() == 2 * T + 1
+    assert (nodes[:, 0] == 1).sum() == T + 1
+    assert (nodes[:, 0] == 2).sum() == 1
+    assert plan.info.slots_fwd == 2 * 3 + 2 * len(nodes) + T
+
+
+def test_errors(vocab):
+    with pytest.raises(KeyError):
+        Plan(np.array([[44, 0, 0]], dtype=np.int64), vocab)
+    with pytest.raises(KeyError):
+        Plan(np.array([[-1, 0, 0]], dtype=np.int64), vocab)
+    with pytest.raises(ValueError):
+        Plan(np.zeros(5, dtype=np.int64), vocab)
+
+
+def test_blob_sections_and_slots(vocab):
+    prog = synth.synth_programs(9, 40, vocab)
+    plan, nodes = check_against_oracle(prog, vocab)
+    blob = plan.blob()
+    n, nv = 40, len(nodes)
+    off, cnt = plan.section('CLS_FWD_TILES')
+    tiles = blob[off:off + cnt * 8].reshape(cnt, 8)
+    assert cnt == n
+    np.testing.assert_array_equal(tiles[:, 0], 2 * n + plan.roots())     # Y(root) gathered
+    np.testing.assert_array_equal(tiles[:, 2], np.arange(n))
+    off, cnt = plan.section('SCENE_OFFSETS')
+    offs = blob[off:off + cnt]
+    scene = vocab['program_token_to_idx']['scene']
+    per_sample = np.bincount(nodes[nodes[:, 1] == scene, 0], minlength=n)
+    np.testing.assert_array_equal(np.diff(offs), per_sample)
+    off, cnt = plan.section('WG_ITEMS')
+    items = blob[off:off + cnt * 4].reshape(cnt, 4)
+    assert items[:, 2].sum() == nv and items[:, 2].max() <= 16
+    assert plan.slot('Y', 0) == 2 * n and plan.slot('H', 0) == 2 * n + nv
+    assert plan.info.slots_total > plan.info.slots_fwd
+
+
+def test_flops_formula(vocab):
+    prog = synth.synth_programs(1, 64, vocab)
+    plan = Plan(prog, vocab)
+    fwd, both = plan.flops()
+    i = plan.info
+    fixed = 462422016 + 57802752 + 25690112 + 205520896 + 65536
+    assert fwd == 64 * fixed + (i.num_scene + i.num_unary) * 115605504 + i.num_binary * 128450560
+    assert both == 3 * fwd - 64 * 462422016

@@ -1,0 +1,217 @@
+// Layout changes and small elementwise / reduction kernels around the MFMA kernels (gfx950).
+// All of them are HBM-bound; loads and stores are arranged so that a wave touches whole lines.
+#include "vqa_dev.h"
+#include "plan.h"
+
+#define CHECK_LAUNCH(name)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            vqa_set_error(std::string(name ": ") + hipGetErrorString(e_));                    \
+            return VQA_ELAUNCH;                                                               \
+        }                                                                                     \
+    } while (0)
+
+// x [n][Cin][196] (fp32) -> out [n][196][Cpad] (bf16); channels Cin..Cpad-1 are written as zero.
+// Block = one sample x 64 channels, staged through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x,
+                                                           bf16_t* __restrict__ out, int Cin, int Cpad) {
+    __shared__ float tile[64 * 197];
+    const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    const float* xs = x + ((int64_t)n * Cin + c0) * VQA_HW;
+    for (int idx = tid; idx < 64 * VQA_HW; idx += 256) {
+        const int c = idx / VQA_HW, pix = idx - c * VQA_HW;
+        tile[c * 197 + pix] = (c0 + c < Cin) ? xs[idx] : 0.f;
+    }
+    __syncthreads();
+    bf16_t* os = out + (int64_t)n * VQA_HW * Cpad + c0;
+    for (int idx = tid; idx < VQA_HW * 16; idx += 256) {
+        const int pix = idx >> 4, cg = (idx & 15) * 4;
+        u16x4 o = {f2bf(tile[(cg + 0) * 197 + pix]), f2bf(tile[(cg + 1) * 197 + pix]),
+                   f2bf(tile[(cg + 2) * 197 + pix]), f2bf(tile[(cg + 3) * 197 + pix])};
+        *(u16x4*)(os + (int64_t)pix * Cpad + cg) = o;
+    }
+}
+
+extern "C" int vqa_nchw_to_nhwc(const float* x, void* out, int32_t N, int32_t Cin, int32_t Cpad, void* stream) {
+    if (!x || !out || N <= 0 || Cin <= 0 || Cpad < Cin || Cpad % 64 != 0) {
+        vqa_set_error("vqa_nchw_to_nhwc: bad argument");
+        return VQA_EINVAL;
+    }
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(Cpad / 64, N), dim3(256), 0, (hipStream_t)stream,
+                       x, (bf16_t*)out, Cin, Cpad);
+    CHECK_LAUNCH("vqa_nchw_to_nhwc");
+    return VQA_OK;
+}
+
+extern "C" int vqa_fc_weight_to_nhwc(const float* w, void* out, int32_t F, int32_t Fpad, int32_t P, void* stream) {
+    if (Fpad < F || !w || !out || P % 64 != 0) { vqa_set_error("vqa_fc_weight_to_nhwc: bad argument"); return VQA_EINVAL; }
+    return vqa_nchw_to_nhwc(w, out, F, P, P, stream);
+}
+
+// in [n][196][C] (bf16 or fp32) -> out [n][C][196] fp32
+template <typename Tin>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const Tin* __restrict__ in, float* __restrict__ out, int C) {
+    __shared__ float tile[64 * 197];
+    const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    const Tin* is = in + (int64_t)n * VQA_HW * C + c0;
+    for (int idx = tid; idx < VQA_HW * 64; idx += 256) {
+        const int pix = idx >> 6, c = idx & 63;
+        float v;
+        if constexpr (sizeof(Tin) == 2) v = bf2f(is[(int64_t)pix * C + c]);
+        else v = is[(int64_t)pix * C + c];
+        tile[c * 197 + pix] = v;
+    }
+    __syncthreads();
+    float* os = out + ((int64_t)n * C + c0) * VQA_HW;
+    for (int idx = tid; idx < 64 * VQA_HW; idx += 256) {
+        const int c = idx / VQA_HW, pix = idx - c * VQA_HW;
+        os[idx] = tile[c * 197 + pix];
+    }
+}
+
+extern "C" int vqa_nhwc_to_nchw(const void* x, float* out, int32_t N, int32_t C, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || C % 64 != 0) { vqa_set_error("vqa_nhwc_to_nchw: bad argument"); return VQA_EINVAL; }
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(C / 64, N), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, out, C);
+    CHECK_LAUNCH("vqa_nhwc_to_nchw");
+    return VQA_OK;
+}
+
+extern "C" int vqa_fc_grad_from_nhwc(const float* g, float* out, int32_t F, int32_t P, void* stream) {
+    if (!g || !out || F <= 0 || P <= 0 || P % 64 != 0) { vqa_set_error("vqa_fc_grad_from_nhwc: bad argument"); return VQA_EINVAL; }
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(P / 64, F), dim3(256), 0, (hipStream_t)stream, g, out, P);
+    CHECK_LAUNCH("vqa_fc_grad_from_nhwc");
+    return VQA_OK;
+}
+
+__global__ void cast_pad_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int rows, int cols,
+                                int rows_pad, int cols_pad) {
+    const int64_t total = (int64_t)rows_pad * cols_pad;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = idx / cols_pad, c = idx - (int64_t)r * cols_pad;
+        out[idx] = (r < rows && c < cols) ? f2bf(w[(int64_t)r * cols + c]) : (bf16_t)0;
+    }
+}
+
+extern "C" int vqa_cast_pad(const float* w, void* out, int32_t rows, int32_t cols, int32_t rows_pad,
+                            int32_t cols_pad, void* stream) {
+    if (!w || !out || rows <= 0 || cols <= 0 || rows_pad < rows || cols_pad < cols) {
+        vqa_set_error("vqa_cast_pad: bad argument");
+        return VQA_EINVAL;
+    }
+    const int64_t total = (int64_t)rows_pad * cols_pad;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, w, (bf16_t*)out, rows, cols, rows_pad, cols_pad);
+    CHECK_LAUNCH("vqa_cast_pad");
+    return VQA_OK;
+}
+
+// out[row][col] = act(sum_s acc[s][row][col] + bias[col]); the sum over s folds split-K slabs
+__global__ void bias_act_kernel(const float* __restrict__ acc, const float* __restrict__ bias,
+                                bf16_t* __restrict__ out, int rows, int cols, int64_t ld_acc, int64_t ld_out,
+                                int relu, int slabs, int64_t slab_stride) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = idx / cols, c = idx - (int64_t)r * cols;
+        float v = bias ? bias[c] : 0.f;
+        for (int s = 0; s < slabs; s++) v += acc[s * slab_stride + r * ld_acc + c];
+        if (relu) v = fmaxf(v, 0.f);
+        out[r * ld_out + c] = f2bf(v);
+    }
+}
+__global__ void bias_act_f32_kernel(const float* __restrict__ acc, const float* __restrict__ bias,
+                                    float* __restrict__ out, int rows, int cols, int64_t ld_acc, int64_t ld_out,
+                                    int relu, int slabs, int64_t slab_stride) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = idx / cols, c = idx - (int64_t)r * cols;
+        float v = bias ? bias[c] : 0.f;
+        for (int s = 0; s < slabs; s++) v += acc[s * slab_stride + r * ld_acc + c];
+        if (relu) v = fmaxf(v, 0.f);
+        out[r * ld_out + c] = v;
+    }
+}
+
+extern "C" int vqa_bias_act(const float* acc, const float* bias, void* out, int32_t rows, int32_t cols,
+                            int64_t ld_acc, int64_t ld_out, int32_t relu, int32_t slabs,
+                            int64_t slab_stride, int32_t out_f32, void* stream) {
+    if (!acc || !out || rows <= 0 || cols <= 0 || slabs < 1) { vqa_set_error("vqa_bias_act: bad argument"); return VQA_EINVAL; }
+    const int64_t total = (int64_t)rows * cols;
+    dim3 grid((int)std::min<int64_t>((total + 255) / 256, 4096));
+    if (out_f32)
+        hipLaunchKernelGGL(bias_act_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, acc, bias, (float*)out,
+                           rows, cols, ld_acc, ld_out, relu, slabs, slab_stride);
+    else
+        hipLaunchKernelGGL(bias_act_kernel, grid, dim3(256), 0, (hipStream_t)stream, acc, bias, (bf16_t*)out,
+                           rows, cols, ld_acc, ld_out, relu, slabs, slab_stride);
+    CHECK_LAUNCH("vqa_bias_act");
+    return VQA_OK;
+}
+
+// out[col] += sum_rows x[row][col]; block = 64 columns x 4 row lanes, grid.y splits the rows
+__global__ __launch_bounds__(256) void col_sum_kernel(const void* __restrict__ x, float* __restrict__ out, int rows,
+                                                      int cols, int64_t ld, int is_bf16) {
+    __shared__ float red[256];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < cols)
+        for (int r = blockIdx.y * 4 + part; r < rows; r += gridDim.y * 4)
+            s += is_bf16 ? bf2f(((const bf16_t*)x)[r * ld + col]) : ((const float*)x)[r * ld + col];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (part == 0 && col < cols)
+        atomicAdd(out + col, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+extern "C" int vqa_col_sum(const void* x, float* out, int32_t rows, int32_t cols, int64_t ld, int32_t is_bf16,
+                           void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) { vqa_set_error("vqa_col_sum: bad argument"); return VQA_EINVAL; }
+    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, std::min(32, (rows + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, out, rows, cols, ld, is_bf16);
+    CHECK_LAUNCH("vqa_col_sum");
+    return VQA_OK;
+}
+
+// dst slot d <- (sum over src slots offsets[d]..offsets[d+1]) * (mask slot > 0), 8 bf16 per lane
+__global__ __launch_bounds__(256) void slot_sum_mask_kernel(bf16_t* __restrict__ arena, const int32_t* __restrict__ offsets,
+                                                            const int32_t* __restrict__ src_slots,
+                                                            const int32_t* __restrict__ dst_slots,
+                                                            const int32_t* __restrict__ mask_slots, int64_t slot_elems) {
+    const int d = blockIdx.y;
+    const int beg = offsets[d], end = offsets[d + 1];
+    bf16_t* dst = arena + (int64_t)dst_slots[d] * slot_elems;
+    const bf16_t* mk = arena + (int64_t)mask_slots[d] * slot_elems;
+    typedef __attribute__((ext_vector_type(8))) uint16_t u16x8;
+    for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; e < slot_elems;
+         e += (int64_t)gridDim.x * blockDim.x * 8) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = beg; k < end; k++) {
+            const u16x8 v = *(const u16x8*)(arena + (int64_t)src_slots[k] * slot_elems + e);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[j] += bf2f(v[j]);
+        }
+        const u16x8 m = *(const u16x8*)(mk + e);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = ((int16_t)m[j] > 0) ? f2bf(s[j]) : (bf16_t)0;
+        *(u16x8*)(dst + e) = o;
+    }
+}
+
+extern "C" int vqa_slot_sum_mask(void* arena, const int32_t* offsets, const int32_t* src_slots,
+                                 const int32_t* dst_slots, const int32_t* mask_slots, int32_t n_dst,
+                                 int64_t slot_elems, void* stream) {
+    if (!arena || !offsets || !src_slots || !dst_slots || !mask_slots || n_dst <= 0 || slot_elems % 8 != 0) {
+        vqa_set_error("vqa_slot_sum_mask: bad argument");
+        return VQA_EINVAL;
+    }
+    const int bx = (int)std::min<int64_t>((slot_elems / 8 + 255) / 256, 64);
+    hipLaunchKernelGGL(slot_sum_mask_kernel, dim3(bx, n_dst), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)arena, offsets, src_slots, dst_slots, mask_slots, slot_elems);
+    CHECK_LAUNCH("vqa_slot_sum_mask");
+    return VQA_OK;
+}

@@ -1,0 +1,33 @@
+// Host-side plan object behind the opaque vqa_plan handle.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vqa_amd.h"
+
+struct PlanNode { int32_t sample, token, col, child0, child1, level; };
+
+struct PlanLevel {
+    int count = 0, bcount = 0;
+    int off_proj = 0, off_conv1 = 0, off_conv2 = 0, off_dgrad2 = 0, off_dgrad1 = 0, off_dproj = 0;
+};
+
+struct vqa_plan {
+    int N = 0, T = 0, C = 0, V = 0;
+    std::vector<PlanNode> nodes;      // execution order per sample, samples in order
+    std::vector<PlanNode> pending;    // parse scratch
+    std::vector<int32_t> roots;       // node id of each sample's root
+    std::vector<float> used;          // [N][T]
+    std::vector<int32_t> bin_index, scene_index, token_counts;
+    std::vector<std::vector<int>> level_nodes;
+    std::vector<PlanLevel> levels;
+    std::vector<int32_t> blob;
+    int num_scene = 0, num_unary = 0, num_binary = 0, num_levels = 0, max_level_tiles = 0;
+    int slot_F = 0, slot_S0 = 0, slot_Y = 0, slot_H = 0, slot_P = 0, slots_fwd = 0;
+    int slot_dZ = 0, slot_dH = 0, slot_dP = 0, slot_dFp = 0, slot_dF = 0, slot_dS0 = 0, slots_total = 0;
+    int sec_off[VQA_SEC_COUNT] = {0};
+    int sec_cnt[VQA_SEC_COUNT] = {0};
+};
+
+void vqa_set_error(const std::string& s);

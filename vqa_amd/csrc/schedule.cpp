@@ -1,0 +1,391 @@
+// Program scheduler: parse prefix programs with the reference interpreter's rules, bucket the tree
+// nodes of the whole batch by (level, token), and lay out the int32 descriptor blob the device
+// kernels index.  Host code only.
+//
+// Follows Module_Model.py:196-222 (forward_modules_ints_helper):
+//   * a column past the end of the row is an implicit `scene` that is not marked used (:201-203)
+//   * <START> is skipped wherever it appears (:206-208)
+//   * <NULL> is not marked used but still runs as a unary module (:204-205, then :215-221)
+//   * every other token, <END> and <UNK> included, is marked used and runs with the arity of
+//     Program_funcs.py:114-122
+//   * tokens after the root's subtree is complete are never read
+#include "plan.h"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+thread_local std::string g_vqa_error;
+
+void vqa_set_error(const std::string& s) { g_vqa_error = s; }
+
+extern "C" const char* vqa_last_error(void) { return g_vqa_error.c_str(); }
+extern "C" int vqa_version(void) { return 100; }
+
+namespace {
+
+struct Frame { int node; int need; };
+
+// Iterative form of the recursive helper: a stack of open nodes waiting for inputs.
+int parse_row(const int64_t* row, int T, const int8_t* arity, int V, int null_id, int start_id,
+              int scene_id, int sample, vqa_plan* pl, float* used) {
+    std::vector<Frame> stack;
+    int j = 0;
+    const int base = (int)pl->nodes.size();
+    for (;;) {
+        int tok, col;
+        // read one token (skipping <START>) or fall off the row
+        for (;;) {
+            if (j < T) {
+                int64_t v = row[j];
+                if (v < 0 || v >= V) {
+                    vqa_set_error("program token id " + std::to_string((long long)v) +
+                                  " outside the vocabulary (sample " + std::to_string(sample) +
+                                  ", column " + std::to_string(j) + ")");
+                    return VQA_EVOCAB;
+                }
+                tok = (int)v;
+                if (tok == start_id) { j++; continue; }
+                col = j;
+                if (tok != null_id) used[j] = 1.0f;
+                j++;
+            } else {
+                tok = scene_id;
+                col = -1;
+            }
+            break;
+        }
+        PlanNode nd;
+        nd.sample = sample; nd.token = tok; nd.col = col; nd.child0 = nd.child1 = -1; nd.level = 0;
+        const int ar = (tok == scene_id) ? 0 : arity[tok];
+        // post-order numbering: a node gets its id when it completes, so reserve via the stack
+        if (ar == 0) {
+            int id = (int)pl->nodes.size();
+            pl->nodes.push_back(nd);
+            // deliver to parents
+            for (;;) {
+                if (stack.empty()) { pl->roots.push_back(id); (void)base; return VQA_OK; }
+                Frame& f = stack.back();
+                PlanNode& par = pl->pending[f.node];
+                if (par.child0 < 0) par.child0 = id; else par.child1 = id;
+                par.level = std::max(par.level, pl->nodes[id].level + 1);
+                if (--f.need > 0) break;
+                // parent complete: it becomes a real node now
+                int pidx = f.node;
+                stack.pop_back();
+                id = (int)pl->nodes.size();
+                pl->nodes.push_back(pl->pending[pidx]);
+            }
+        } else {
+            pl->pending.push_back(nd);
+            stack.push_back({(int)pl->pending.size() - 1, ar});
+        }
+    }
+}
+
+void push_tile(std::vector<int32_t>& b, int s0, int s1, int d0, int d1, int res, int m0, int m1,
+               int wg) {
+    const int32_t t[8] = {s0, s1, d0, d1, res, m0, m1, wg};
+    b.insert(b.end(), t, t + 8);
+}
+
+}  // namespace
+
+extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
+                                  const int8_t* arity, int32_t V, int32_t null_id,
+                                  int32_t start_id, int32_t scene_id, int32_t C,
+                                  int32_t wgrad_chunk, vqa_plan** out) {
+    if (!programs || !arity || !out || N <= 0 || T <= 0 || V <= 0 || scene_id < 0 ||
+        scene_id >= V || C <= 0 || C % 128 != 0 || wgrad_chunk <= 0) {
+        vqa_set_error("vqa_schedule_build: bad argument");
+        return VQA_EINVAL;
+    }
+    vqa_plan* pl = new (std::nothrow) vqa_plan();
+    if (!pl) { vqa_set_error("out of host memory"); return VQA_EINVAL; }
+    pl->N = N; pl->T = T; pl->C = C; pl->V = V;
+    pl->used.assign((size_t)N * T, 0.0f);
+    for (int i = 0; i < N; i++) {
+        pl->pending.clear();
+        int rc = parse_row(programs + (size_t)i * T, T, arity, V, null_id, start_id, scene_id, i,
+                           pl, pl->used.data() + (size_t)i * T);
+        if (rc) { delete pl; return rc; }
+    }
+    pl->pending.clear();
+    pl->pending.shrink_to_fit();
+
+    const int NV = (int)pl->nodes.size();
+    // kind indices
+    pl->bin_index.assign(NV, -1);
+    pl->scene_index.assign(NV, -1);
+    int nb = 0, ns = 0, nu = 0, maxlev = 0;
+    pl->token_counts.assign(V, 0);
+    for (int v = 0; v < NV; v++) {
+        const PlanNode& nd = pl->nodes[v];
+        pl->token_counts[nd.token]++;
+        if (nd.token == scene_id) pl->scene_index[v] = ns++;
+        else if (nd.child1 >= 0) pl->bin_index[v] = nb++;
+        else nu++;
+        maxlev = std::max(maxlev, nd.level);
+    }
+    pl->num_scene = ns; pl->num_unary = nu; pl->num_binary = nb; pl->num_levels = maxlev + 1;
+
+    // arena slots
+    pl->slot_F = 0; pl->slot_S0 = N; pl->slot_Y = 2 * N; pl->slot_H = 2 * N + NV;
+    pl->slot_P = 2 * N + 2 * NV; pl->slots_fwd = 2 * N + 2 * NV + nb;
+    pl->slot_dZ = pl->slots_fwd; pl->slot_dH = pl->slot_dZ + NV; pl->slot_dP = pl->slot_dH + NV;
+    pl->slot_dFp = pl->slot_dP + nb; pl->slot_dF = pl->slot_dFp + ns; pl->slot_dS0 = pl->slot_dF + N;
+    pl->slots_total = pl->slot_dS0 + N;
+
+    // level buckets: nodes of a level sorted by (token, node id)
+    pl->level_nodes.assign(pl->num_levels, {});
+    for (int v = 0; v < NV; v++) pl->level_nodes[pl->nodes[v].level].push_back(v);
+    for (auto& lv : pl->level_nodes)
+        std::stable_sort(lv.begin(), lv.end(), [&](int a, int b) {
+            return pl->nodes[a].token < pl->nodes[b].token;
+        });
+
+    auto in_slot = [&](int v) {   // slot the residual body of node v reads
+        const PlanNode& nd = pl->nodes[v];
+        if (nd.token == scene_id) return pl->slot_F + nd.sample;
+        if (nd.child1 >= 0) return pl->slot_P + pl->bin_index[v];
+        return pl->slot_Y + nd.child0;
+    };
+
+    std::vector<int32_t>& b = pl->blob;
+    pl->levels.assign(pl->num_levels, {});
+    int max_tiles = 0;
+    for (int L = 0; L < pl->num_levels; L++) {
+        PlanLevel& lv = pl->levels[L];
+        const std::vector<int>& nodes = pl->level_nodes[L];
+        lv.count = (int)nodes.size();
+        max_tiles = std::max(max_tiles, lv.count);
+        // binary nodes of the level keep the same (token, id) order
+        std::vector<int> bins;
+        for (int v : nodes) if (pl->nodes[v].child1 >= 0) bins.push_back(v);
+        lv.bcount = (int)bins.size();
+        lv.off_proj = (int)b.size();
+        for (int v : bins) {
+            const PlanNode& nd = pl->nodes[v];
+            push_tile(b, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
+                      pl->slot_P + pl->bin_index[v], -1, -1, -1, -1, nd.token);
+        }
+        lv.off_conv1 = (int)b.size();
+        for (int v : nodes)
+            push_tile(b, in_slot(v), -1, pl->slot_H + v, -1, -1, -1, -1, pl->nodes[v].token);
+        lv.off_conv2 = (int)b.size();
+        for (int v : nodes)
+            push_tile(b, pl->slot_H + v, -1, pl->slot_Y + v, -1, in_slot(v), -1, -1,
+                      pl->nodes[v].token);
+        // backward: dH = dgrad_conv2(dZ) * (H > 0)
+        lv.off_dgrad2 = (int)b.size();
+        for (int v : nodes)
+            push_tile(b, pl->slot_dZ + v, -1, pl->slot_dH + v, -1, -1, pl->slot_H + v, -1,
+                      pl->nodes[v].token);
+        // d(input) = (dgrad_conv1(dH) + dZ) * (input > 0); a scene node's input is the shared
+        // stem map, so its gradient goes unmasked to a per-node slot and is summed later
+        lv.off_dgrad1 = (int)b.size();
+        for (int v : nodes) {
+            const PlanNode& nd = pl->nodes[v];
+            int dst, mask;
+            if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
+            else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
+            else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
+            push_tile(b, pl->slot_dH + v, -1, dst, -1, pl->slot_dZ + v, mask, -1, nd.token);
+        }
+        lv.off_dproj = (int)b.size();
+        for (int v : bins) {
+            const PlanNode& nd = pl->nodes[v];
+            push_tile(b, pl->slot_dP + pl->bin_index[v], -1, pl->slot_dZ + nd.child0,
+                      pl->slot_dZ + nd.child1, -1, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
+                      nd.token);
+        }
+    }
+    pl->max_level_tiles = max_tiles;
+
+    // per-sample sections
+    auto sec = [&](int id) { pl->sec_off[id] = (int)b.size(); };
+    auto endsec = [&](int id, int count) { pl->sec_cnt[id] = count; };
+    sec(VQA_SEC_STEM0_TILES);
+    for (int i = 0; i < N; i++) push_tile(b, i, -1, pl->slot_S0 + i, -1, -1, -1, -1, 0);
+    endsec(VQA_SEC_STEM0_TILES, N);
+    sec(VQA_SEC_STEM1_TILES);
+    for (int i = 0; i < N; i++) push_tile(b, pl->slot_S0 + i, -1, pl->slot_F + i, -1, -1, -1, -1, 0);
+    endsec(VQA_SEC_STEM1_TILES, N);
+    sec(VQA_SEC_STEM1_DGRAD_TILES);
+    for (int i = 0; i < N; i++)
+        push_tile(b, pl->slot_dF + i, -1, pl->slot_dS0 + i, -1, -1, pl->slot_S0 + i, -1, 0);
+    endsec(VQA_SEC_STEM1_DGRAD_TILES, N);
+    sec(VQA_SEC_CLS_FWD_TILES);
+    for (int i = 0; i < N; i++) push_tile(b, pl->slot_Y + pl->roots[i], -1, i, -1, -1, -1, -1, 0);
+    endsec(VQA_SEC_CLS_FWD_TILES, N);
+    sec(VQA_SEC_CLS_DGRAD_TILES);
+    for (int i = 0; i < N; i++)
+        push_tile(b, i, -1, pl->slot_dZ + pl->roots[i], -1, -1, pl->slot_Y + pl->roots[i], -1, 0);
+    endsec(VQA_SEC_CLS_DGRAD_TILES, N);
+
+    auto slot_list = [&](int id, int base_slot) {
+        sec(id);
+        for (int i = 0; i < N; i++) b.push_back(base_slot + i);
+        endsec(id, N);
+    };
+    slot_list(VQA_SEC_SLOTS_IDENT, 0);
+    slot_list(VQA_SEC_SLOTS_S0, pl->slot_S0);
+    slot_list(VQA_SEC_SLOTS_F, pl->slot_F);
+    slot_list(VQA_SEC_SLOTS_DF, pl->slot_dF);
+    slot_list(VQA_SEC_SLOTS_DS0, pl->slot_dS0);
+    sec(VQA_SEC_SLOTS_ROOTY);
+    for (int i = 0; i < N; i++) b.push_back(pl->slot_Y + pl->roots[i]);
+    endsec(VQA_SEC_SLOTS_ROOTY, N);
+
+    // sample-chunk work items (one weight group) for the stem / classifier weight gradients
+    sec(VQA_SEC_SAMPLE_ITEMS);
+    int nitems = 0;
+    for (int s = 0; s < N; s += wgrad_chunk, nitems++) {
+        const int32_t it[4] = {0, s, std::min(wgrad_chunk, N - s), 0};
+        b.insert(b.end(), it, it + 4);
+    }
+    endsec(VQA_SEC_SAMPLE_ITEMS, nitems);
+
+    // scene fan-in (CSR by sample)
+    std::vector<std::vector<int>> scenes(N);
+    for (int v = 0; v < NV; v++)
+        if (pl->scene_index[v] >= 0) scenes[pl->nodes[v].sample].push_back(pl->slot_dFp + pl->scene_index[v]);
+    sec(VQA_SEC_SCENE_OFFSETS);
+    int run = 0;
+    for (int i = 0; i < N; i++) { b.push_back(run); run += (int)scenes[i].size(); }
+    b.push_back(run);
+    endsec(VQA_SEC_SCENE_OFFSETS, N + 1);
+    sec(VQA_SEC_SCENE_SRC);
+    for (int i = 0; i < N; i++) for (int s : scenes[i]) b.push_back(s);
+    endsec(VQA_SEC_SCENE_SRC, run);
+
+    // module weight gradients: nodes grouped by token, cut into items of <= wgrad_chunk nodes
+    std::vector<std::vector<int>> by_tok(V);
+    for (int v = 0; v < NV; v++) by_tok[pl->nodes[v].token].push_back(v);
+    std::vector<int32_t> items, src_c1, dy_c1, src_c2, dy_c2;
+    std::vector<int32_t> pitems, psrc0, psrc1, pdy;
+    for (int t = 0; t < V; t++) {
+        const std::vector<int>& vs = by_tok[t];
+        if (vs.empty()) continue;
+        for (size_t s = 0; s < vs.size(); s += wgrad_chunk) {
+            const int32_t it[4] = {t, (int32_t)src_c1.size(),
+                                   (int32_t)std::min<size_t>(wgrad_chunk, vs.size() - s), 0};
+            items.insert(items.end(), it, it + 4);
+            for (size_t k = s; k < s + it[2]; k++) {
+                int v = vs[k];
+                src_c1.push_back(in_slot(v)); dy_c1.push_back(pl->slot_dH + v);
+                src_c2.push_back(pl->slot_H + v); dy_c2.push_back(pl->slot_dZ + v);
+            }
+        }
+        if (pl->nodes[vs[0]].child1 >= 0) {
+            for (size_t s = 0; s < vs.size(); s += wgrad_chunk) {
+                const int32_t it[4] = {t, (int32_t)psrc0.size(),
+                                       (int32_t)std::min<size_t>(wgrad_chunk, vs.size() - s), 0};
+                pitems.insert(pitems.end(), it, it + 4);
+                for (size_t k = s; k < s + it[2]; k++) {
+                    int v = vs[k];
+                    psrc0.push_back(pl->slot_Y + pl->nodes[v].child0);
+                    psrc1.push_back(pl->slot_Y + pl->nodes[v].child1);
+                    pdy.push_back(pl->slot_dP + pl->bin_index[v]);
+                }
+            }
+        }
+    }
+    auto put = [&](int id, const std::vector<int32_t>& v, int count) {
+        sec(id); b.insert(b.end(), v.begin(), v.end()); endsec(id, count);
+    };
+    put(VQA_SEC_WG_ITEMS, items, (int)items.size() / 4);
+    put(VQA_SEC_WG_SRC_C1, src_c1, (int)src_c1.size());
+    put(VQA_SEC_WG_DY_C1, dy_c1, (int)dy_c1.size());
+    put(VQA_SEC_WG_SRC_C2, src_c2, (int)src_c2.size());
+    put(VQA_SEC_WG_DY_C2, dy_c2, (int)dy_c2.size());
+    put(VQA_SEC_WG_PITEMS, pitems, (int)pitems.size() / 4);
+    put(VQA_SEC_WG_PSRC0, psrc0, (int)psrc0.size());
+    put(VQA_SEC_WG_PSRC1, psrc1, (int)psrc1.size());
+    put(VQA_SEC_WG_PDY, pdy, (int)pdy.size());
+    if (b.empty()) b.push_back(0);
+    *out = pl;
+    return VQA_OK;
+}
+
+extern "C" void vqa_plan_free(vqa_plan* plan) { delete plan; }
+
+extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
+    if (!pl || !o) { vqa_set_error("null plan"); return VQA_EINVAL; }
+    std::memset(o, 0, sizeof(*o));
+    o->N = pl->N; o->T = pl->T; o->C = pl->C;
+    o->num_nodes = (int)pl->nodes.size();
+    o->num_scene = pl->num_scene; o->num_unary = pl->num_unary; o->num_binary = pl->num_binary;
+    o->num_levels = pl->num_levels;
+    o->slots_fwd = pl->slots_fwd; o->slots_total = pl->slots_total;
+    o->blob_words = (int)pl->blob.size();
+    o->wgrad_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
+    o->max_level_tiles = pl->max_level_tiles;
+    return VQA_OK;
+}
+
+extern "C" int vqa_plan_used_fns(const vqa_plan* pl, float* out) {
+    if (!pl || !out) { vqa_set_error("null argument"); return VQA_EINVAL; }
+    std::memcpy(out, pl->used.data(), pl->used.size() * sizeof(float));
+    return VQA_OK;
+}
+
+extern "C" int vqa_plan_nodes(const vqa_plan* pl, int32_t* out) {
+    if (!pl || !out) { vqa_set_error("null argument"); return VQA_EINVAL; }
+    for (size_t v = 0; v < pl->nodes.size(); v++) {
+        const PlanNode& n = pl->nodes[v];
+        int32_t* o = out + v * 6;
+        o[0] = n.sample; o[1] = n.token; o[2] = n.col; o[3] = n.child0; o[4] = n.child1; o[5] = n.level;
+    }
+    return VQA_OK;
+}
+
+extern "C" int vqa_plan_level_nodes(const vqa_plan* pl, int32_t level, int32_t* out, int32_t cap) {
+    if (!pl || level < 0 || level >= pl->num_levels) return -1;
+    const std::vector<int>& lv = pl->level_nodes[level];
+    if (out) for (int i = 0; i < (int)lv.size() && i < cap; i++) out[i] = lv[i];
+    return (int)lv.size();
+}
+
+extern "C" int vqa_plan_token_counts(const vqa_plan* pl, int32_t* out) {
+    if (!pl || !out) { vqa_set_error("null argument"); return VQA_EINVAL; }
+    std::memcpy(out, pl->token_counts.data(), pl->token_counts.size() * sizeof(int32_t));
+    return VQA_OK;
+}
+
+extern "C" int vqa_plan_roots(const vqa_plan* pl, int32_t* out) {
+    if (!pl || !out) { vqa_set_error("null argument"); return VQA_EINVAL; }
+    std::memcpy(out, pl->roots.data(), pl->roots.size() * sizeof(int32_t));
+    return VQA_OK;
+}
+
+extern "C" int vqa_plan_blob(const vqa_plan* pl, int32_t* out) {
+    if (!pl || !out) { vqa_set_error("null argument"); return VQA_EINVAL; }
+    std::memcpy(out, pl->blob.data(), pl->blob.size() * sizeof(int32_t));
+    return VQA_OK;
+}
+
+extern "C" int vqa_plan_section(const vqa_plan* pl, int32_t id, int32_t* offset, int32_t* count) {
+    if (!pl || id < 0 || id >= VQA_SEC_COUNT || !offset || !count) {
+        vqa_set_error("vqa_plan_section: bad argument");
+        return VQA_EINVAL;
+    }
+    *offset = pl->sec_off[id]; *count = pl->sec_cnt[id];
+    return VQA_OK;
+}
+
+extern "C" int32_t vqa_plan_slot(const vqa_plan* pl, int32_t which, int32_t index) {
+    if (!pl || index < 0) return -1;
+    const int NV = (int)pl->nodes.size();
+    switch (which) {
+        case 0: return index < pl->N ? pl->slot_F + index : -1;
+        case 1: return index < pl->N ? pl->slot_S0 + index : -1;
+        case 2: return index < NV ? pl->slot_Y + index : -1;
+        case 3: return index < NV ? pl->slot_H + index : -1;
+        case 4: return index < NV ? pl->slot_dZ + index : -1;
+        case 5: return index < NV ? pl->slot_dH + index : -1;
+        case 6: return index < pl->N ? pl->slot_dF + index : -1;
+        case 7: return index < pl->N ? pl->slot_dS0 + index : -1;
+        default: return -1;
+    }
+}

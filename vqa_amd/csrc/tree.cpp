@@ -1,0 +1,132 @@
+// Level-by-level execution of the whole batch's module trees: the replacement for the per-sample
+// recursion of Module_Model.py:224-233 and for autograd's walk back over it.  Host code; it only
+// fills parameter blocks and enqueues the grouped kernels of conv.hip / wgrad.hip / misc.hip.
+#include "plan.h"
+
+namespace {
+
+vqa_conv_params base_conv(const vqa_plan* pl, const vqa_tree_ctx* c) {
+    vqa_conv_params p = {};
+    p.src = p.res = p.mask = c->arena;
+    p.dst = c->arena;
+    const int64_t slot = (int64_t)VQA_HW * pl->C;
+    p.src_slot_stride = p.dst_slot_stride = slot;
+    p.src_pix_stride = p.dst_pix_stride = pl->C;
+    p.k_chunks = pl->C / 128;
+    p.n_out = pl->C;
+    return p;
+}
+
+const vqa_conv_tile* tiles_at(const vqa_tree_ctx* c, int word_off) {
+    return (const vqa_conv_tile*)(c->blob + word_off);
+}
+
+}  // namespace
+
+extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void* stream) {
+    if (!pl || !c || !c->arena || !c->blob || !c->w_conv1 || !c->w_conv2 || !c->b_conv1 || !c->b_conv2 ||
+        c->C != pl->C || (pl->num_binary > 0 && (!c->w_proj || !c->b_proj))) {
+        vqa_set_error("vqa_tree_forward: bad argument");
+        return VQA_EINVAL;
+    }
+    const int cc = pl->C / 128;
+    const int64_t w33 = (int64_t)9 * pl->C * pl->C, w11 = (int64_t)2 * pl->C * pl->C;
+    for (int L = 0; L < pl->num_levels; L++) {
+        const PlanLevel& lv = pl->levels[L];
+        int rc;
+        if (lv.bcount > 0) {   // P = relu(proj([x; y]) + b)   Module_Model.py:38-39
+            vqa_conv_params p = base_conv(pl, c);
+            p.w = c->w_proj; p.bias = c->b_proj; p.w_group_stride = w11;
+            p.tiles = tiles_at(c, lv.off_proj); p.num_tiles = lv.bcount;
+            p.k_chunks = 2 * cc; p.pair_chunks = cc;
+            p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
+            if ((rc = vqa_conv_tiles(&p, 1, stream))) return rc;
+        }
+        {                      // H = relu(conv1(in) + b1)     Layers.py:33 / Module_Model.py:47
+            vqa_conv_params p = base_conv(pl, c);
+            p.w = c->w_conv1; p.bias = c->b_conv1; p.w_group_stride = w33;
+            p.tiles = tiles_at(c, lv.off_conv1); p.num_tiles = lv.count;
+            p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
+            if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+        }
+        {                      // Y = relu(in + conv2(H) + b2) Layers.py:33-36
+            vqa_conv_params p = base_conv(pl, c);
+            p.w = c->w_conv2; p.bias = c->b_conv2; p.w_group_stride = w33;
+            p.tiles = tiles_at(c, lv.off_conv2); p.num_tiles = lv.count;
+            p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
+            if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+        }
+    }
+    return VQA_OK;
+}
+
+extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void* stream) {
+    if (!pl || !c || !c->arena || !c->blob || !c->wd_conv1 || !c->wd_conv2 || !c->g_conv1 || !c->g_conv2 ||
+        !c->gb_conv1 || !c->gb_conv2 || c->C != pl->C ||
+        (pl->num_binary > 0 && (!c->wd_proj || !c->g_proj || !c->gb_proj))) {
+        vqa_set_error("vqa_tree_backward: bad argument");
+        return VQA_EINVAL;
+    }
+    const int cc = pl->C / 128;
+    const int64_t w33 = (int64_t)9 * pl->C * pl->C, w11 = (int64_t)2 * pl->C * pl->C;
+    const int64_t slot = (int64_t)VQA_HW * pl->C;
+    int rc;
+    for (int L = pl->num_levels - 1; L >= 0; L--) {
+        const PlanLevel& lv = pl->levels[L];
+        {   // dH = dgrad_conv2(dZ) * (H > 0)
+            vqa_conv_params p = base_conv(pl, c);
+            p.w = c->wd_conv2; p.w_group_stride = w33;
+            p.tiles = tiles_at(c, lv.off_dgrad2); p.num_tiles = lv.count;
+            if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+        }
+        {   // d(in) = (dgrad_conv1(dH) + dZ) * (in > 0)
+            vqa_conv_params p = base_conv(pl, c);
+            p.w = c->wd_conv1; p.w_group_stride = w33;
+            p.tiles = tiles_at(c, lv.off_dgrad1); p.num_tiles = lv.count;
+            if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+        }
+        if (lv.bcount > 0) {   // [dx; dy] = dP * Wproj, each masked by its own child's output
+            vqa_conv_params p = base_conv(pl, c);
+            p.w = c->wd_proj; p.w_group_stride = w11;
+            p.tiles = tiles_at(c, lv.off_dproj); p.num_tiles = lv.bcount;
+            p.n_out = 2 * pl->C; p.pair_out = cc;
+            if ((rc = vqa_conv_tiles(&p, 1, stream))) return rc;
+        }
+    }
+    // gradient of the stem output: sum over the scene nodes of each sample, times (F > 0)
+    rc = vqa_slot_sum_mask(c->arena, c->blob + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
+                           c->blob + pl->sec_off[VQA_SEC_SCENE_SRC], c->blob + pl->sec_off[VQA_SEC_SLOTS_DF],
+                           c->blob + pl->sec_off[VQA_SEC_SLOTS_F], pl->N, slot, stream);
+    if (rc) return rc;
+
+    // weight gradients of every module, grouped by token
+    vqa_wgrad_params w = {};
+    w.src = w.dy = c->arena;
+    w.src_slot_stride = w.dy_slot_stride = slot;
+    w.src_pix_stride = w.dy_pix_stride = pl->C;
+    w.n_out = pl->C;
+    w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_ITEMS]);
+    w.num_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
+    w.k_chunks = cc;
+    w.dw_group_stride = w33;
+    w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C1];
+    w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C1];
+    w.dw = c->g_conv1; w.db = c->gb_conv1;
+    if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
+    w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C2];
+    w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C2];
+    w.dw = c->g_conv2; w.db = c->gb_conv2;
+    if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
+    if (pl->sec_cnt[VQA_SEC_WG_PITEMS] > 0) {
+        w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_PITEMS]);
+        w.num_items = pl->sec_cnt[VQA_SEC_WG_PITEMS];
+        w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_PSRC0];
+        w.src1_slots = c->blob + pl->sec_off[VQA_SEC_WG_PSRC1];
+        w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_PDY];
+        w.k_chunks = 2 * cc; w.pair_chunks = cc;
+        w.dw_group_stride = w11;
+        w.dw = c->g_proj; w.db = c->gb_proj;
+        if ((rc = vqa_wgrad_tiles(&w, 1, stream))) return rc;
+    }
+    return VQA_OK;
+}

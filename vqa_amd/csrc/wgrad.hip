@@ -1,0 +1,204 @@
+// Grouped convolution weight gradient (gfx950, bf16 MFMA, fp32 atomic accumulation).
+//
+//   dW[group][tap][i][o] += sum_{node in group} sum_{pixel} src_node(pixel + tap)[i] * dy_node(pixel)[o]
+//
+// The contraction runs over pixels, which is the slow axis of the channels-last maps, so both MFMA
+// operands are read from LDS with the transposing read (ds_read_b64_tr_b16).  One workgroup
+// (8 waves) owns a work item (<= wgrad_chunk nodes of one weight group) x 64 output channels x
+// 128 source channels; wave w owns source channels [16w, 16w+16) x 4 tiles of 16 output channels x
+// every tap, so its accumulators (taps x 4 tiles) stay in registers across all nodes of the item
+// and leave once, as fp32 atomics.  A k-step of 32 is two image rows of 16 columns; columns 14, 15
+// of the dy image are zero, the source image has a zero border.
+//
+// Replaces autograd's per-call conv weight/bias gradients and their sum over every use of a
+// token's module (Train_model.py:313 over Module_Model.py:221).
+#include "vqa_dev.h"
+#include "plan.h"
+
+#define XH_STRIDE 288
+#define XH_POS 264
+#define XH_BYTES (XH_POS * XH_STRIDE)        // 76032
+#define DY_STRIDE 160
+#define DY_POS 224
+#define DY_BYTES (DY_POS * DY_STRIDE)        // 35840
+#define WGRAD_LDS (XH_BYTES + DY_BYTES)
+
+template <int TAPS>
+__global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xh = smem;
+    char* dyt = smem + XH_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4, q = l15 >> 2, pp = lane & 3;
+    const vqa_wgrad_item it = p.items[blockIdx.x];
+    const int oslice = blockIdx.y, kchunk = blockIdx.z;
+
+    for (int i = tid; i < WGRAD_LDS / 16; i += 512) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+
+    int which = 0, choff = kchunk * 128;
+    if (p.pair_chunks > 0) { which = kchunk / p.pair_chunks; choff = (kchunk % p.pair_chunks) * 128; }
+    const int32_t* sslots = which ? p.src1_slots : p.src_slots;
+
+    // Prefetch registers are named scalars (not arrays): loop-carried arrays end up in scratch.
+    uint4 x0, x1, x2, x3, x4, x5, x6, d0, d1, d2, d3;
+#define XLOAD(i, var)                                                                          \
+    {                                                                                          \
+        const int e = tid + 512 * i, pix = min(e >> 4, VQA_HW - 1), pc = e & 15;               \
+        var = *(const uint4*)(sp + (int64_t)pix * p.src_pix_stride * 2 + pc * 16);             \
+    }
+#define DLOAD(i, var)                                                                          \
+    {                                                                                          \
+        const int e = tid + 512 * i, pix = min(e >> 3, VQA_HW - 1), pc = e & 7;                \
+        var = *(const uint4*)(dp + (int64_t)pix * p.dy_pix_stride * 2 + pc * 16);              \
+    }
+#define LOAD_NODE(n)                                                                           \
+    {                                                                                          \
+        const int ss = sslots[it.first + (n)], ds = p.dy_slots[it.first + (n)];                \
+        const char* sp = (const char*)p.src + ((int64_t)ss * p.src_slot_stride + choff) * 2;   \
+        const char* dp = (const char*)p.dy + ((int64_t)ds * p.dy_slot_stride + oslice * 64) * 2; \
+        XLOAD(0, x0) XLOAD(1, x1) XLOAD(2, x2) XLOAD(3, x3) XLOAD(4, x4) XLOAD(5, x5) XLOAD(6, x6) \
+        DLOAD(0, d0) DLOAD(1, d1) DLOAD(2, d2) DLOAD(3, d3)                                    \
+    }
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define XSTORE(i, var)                                                                         \
+    {                                                                                          \
+        const int e = tid + 512 * i, pix = e >> 4, pc = e & 15;                                \
+        if (pix < VQA_HW) {                                                                    \
+            const int y = pix / 14, x = pix - y * 14;                                          \
+            *(uint4*)(xh + ((y + 1) * 16 + x + 1) * XH_STRIDE + pc * 16) = var;                \
+        }                                                                                      \
+    }
+#define DSTORE(i, var)                                                                         \
+    {                                                                                          \
+        const int e = tid + 512 * i, pix = e >> 3, pc = e & 7;                                 \
+        if (pix < VQA_HW) {                                                                    \
+            const int y = pix / 14, x = pix - y * 14;                                          \
+            *(uint4*)(dyt + (y * 16 + x) * DY_STRIDE + pc * 16) = var;                         \
+            bsum[0] += __uint_as_float(var.x << 16); bsum[1] += __uint_as_float(var.x & 0xFFFF0000u); \
+            bsum[2] += __uint_as_float(var.y << 16); bsum[3] += __uint_as_float(var.y & 0xFFFF0000u); \
+            bsum[4] += __uint_as_float(var.z << 16); bsum[5] += __uint_as_float(var.z & 0xFFFF0000u); \
+            bsum[6] += __uint_as_float(var.w << 16); bsum[7] += __uint_as_float(var.w & 0xFFFF0000u); \
+        }                                                                                      \
+    }
+#define STORE_NODE()                                                                           \
+    {                                                                                          \
+        XSTORE(0, x0) XSTORE(1, x1) XSTORE(2, x2) XSTORE(3, x3) XSTORE(4, x4) XSTORE(5, x5) XSTORE(6, x6) \
+        DSTORE(0, d0) DSTORE(1, d1) DSTORE(2, d2) DSTORE(3, d3)                                \
+    }
+
+    f32x4 acc[TAPS][4];
+#pragma unroll
+    for (int t = 0; t < TAPS; t++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // lane's transposed-read addresses at k-step 0, read r = 0: position (row g>>1, col 4*(g&1)+q)
+    const int prow = g >> 1, pcol = 4 * (g & 1) + q;
+    const int xoff = (prow * 16 + pcol) * XH_STRIDE + (wave * 16 + 4 * pp) * 2;   // + tap, + kk, + r
+    const int doff = (prow * 16 + pcol) * DY_STRIDE + (4 * pp) * 2;               // + 32*ot, + kk, + r
+
+    LOAD_NODE(0)
+    for (int n = 0; n < it.count; n++) {
+        __syncthreads();          // zero fill done / previous node's reads done
+        STORE_NODE()
+        __syncthreads();
+        LOAD_NODE(min(n + 1, it.count - 1))   // unconditional: a predicated prefetch spills
+#pragma unroll 1
+        for (int kk = 0; kk < 7; kk++) {
+            const char* xb = xh + xoff + kk * 32 * XH_STRIDE;
+            const char* db = dyt + doff + kk * 32 * DY_STRIDE;
+            bf16x8 bf[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+                bf[o] = frag_from_tr(lds_tr4(db + o * 32), lds_tr4(db + o * 32 + 8 * DY_STRIDE));
+#pragma unroll
+            for (int t = 0; t < TAPS; t++) {
+                const int tapoff = (TAPS == 9) ? ((t / 3) * 16 + (t % 3)) : 17;
+                const bf16x8 af = frag_from_tr(lds_tr4(xb + tapoff * XH_STRIDE),
+                                               lds_tr4(xb + (tapoff + 8) * XH_STRIDE));
+#pragma unroll
+                for (int o = 0; o < 4; o++) acc[t][o] = mma16(af, bf[o], acc[t][o]);
+            }
+        }
+    }
+
+    // accumulators out: row = source channel, col = output channel
+    const int k_in = p.k_chunks * 128;
+    float* dw = p.dw + (int64_t)it.group * p.dw_group_stride;
+#pragma unroll
+    for (int t = 0; t < TAPS; t++)
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = kchunk * 128 + wave * 16 + g * 4 + r;
+                const int oc = oslice * 64 + o * 16 + l15;
+                atomicAdd(dw + ((int64_t)t * k_in + i) * p.n_out + oc, acc[t][o][r]);
+            }
+
+    if (p.db && kchunk == 0) {
+        __syncthreads();
+        float* red = (float*)smem;       // [512][8]
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[tid * 8 + j] = bsum[j];
+        __syncthreads();
+        if (tid < 64) {
+            const int pc = tid >> 3, j = tid & 7;
+            float s = 0.f;
+            for (int u = pc; u < 512; u += 8) s += red[u * 8 + j];
+            atomicAdd(p.db + (int64_t)it.group * p.n_out + oslice * 64 + tid, s);
+        }
+    }
+}
+
+extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* stream) {
+    if (!p || !p->src || !p->dy || !p->items || !p->src_slots || !p->dy_slots || !p->dw ||
+        (taps != 9 && taps != 1) || p->k_chunks <= 0 || p->n_out <= 0 || p->n_out % 64 != 0 ||
+        p->src_pix_stride % 8 != 0 || p->dy_pix_stride % 8 != 0 || p->num_items < 0 ||
+        (p->pair_chunks > 0 && !p->src1_slots)) {
+        vqa_set_error("vqa_wgrad_tiles: bad argument");
+        return VQA_EINVAL;
+    }
+    if (p->num_items == 0) return VQA_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_tiles_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS);
+        (void)hipFuncSetAttribute((const void*)wgrad_tiles_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS);
+        attr_set = true;
+    }
+    dim3 grid(p->num_items, p->n_out / 64, p->k_chunks), block(512);
+    if (taps == 9) hipLaunchKernelGGL(wgrad_tiles_kernel<9>, grid, block, WGRAD_LDS, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(wgrad_tiles_kernel<1>, grid, block, WGRAD_LDS, (hipStream_t)stream, *p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_wgrad_tiles: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}
+
+// dW accumulators [group][tap][k][n] fp32 -> torch's [n][k][tap] per group
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ dw, float* __restrict__ out,
+                                        int n_out, int k_in, int taps, int64_t out_g_stride) {
+    const int g = blockIdx.y;
+    const int64_t per = (int64_t)n_out * k_in * taps;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int t = idx % taps;
+        const int64_t r = idx / taps;
+        const int k = r % k_in, n = r / k_in;
+        out[g * out_g_stride + idx] = dw[g * per + ((int64_t)t * k_in + k) * n_out + n];
+    }
+}
+
+extern "C" int vqa_unpack_conv_grad(const float* dw, float* out, int32_t groups, int32_t n_out,
+                                    int32_t k_in, int32_t taps, int64_t out_g_stride, void* stream) {
+    if (!dw || !out || groups <= 0 || n_out <= 0 || k_in <= 0 || taps <= 0) {
+        vqa_set_error("vqa_unpack_conv_grad: bad argument");
+        return VQA_EINVAL;
+    }
+    const int64_t per = (int64_t)n_out * k_in * taps;
+    int blocks = (int)std::min<int64_t>((per + 255) / 256, 2048);
+    hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream,
+                       dw, out, n_out, k_in, taps, out_g_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_unpack_conv_grad: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}

@@ -1,0 +1,107 @@
+"""Host wrapper of the program scheduler in libvqa_amd.so (vqa_schedule_build).
+
+The scheduler replaces the per-sample recursion of `forward_modules_ints_helper`
+(`Module_Model.py:196-222`): it parses every prefix program with the reference's rules and buckets
+the tree nodes of the whole batch by (level, token).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, vocab as V
+
+
+class Plan:
+    """Parsed + bucketed programs of one batch.  Owns the native plan handle."""
+
+    def __init__(self, programs, vocab, module_dim=128, wgrad_chunk=16):
+        lib = _lib.load()
+        prog = np.ascontiguousarray(np.asarray(programs), dtype=np.int64)
+        if prog.ndim != 2:
+            raise ValueError('Unregonized program format')      # Module_Model.py:245
+        t2i = vocab['program_token_to_idx']
+        arity = np.asarray(V.arity_table(vocab), dtype=np.int8)
+        self._lib = lib
+        self._h = C.c_void_p()
+        n, t = prog.shape
+        _lib.check(lib.vqa_schedule_build(
+            prog.ctypes.data_as(_lib.i64p), n, t, arity.ctypes.data_as(_lib.i8p), len(arity),
+            t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk,
+            C.byref(self._h)))
+        self.info = _lib.PlanInfo()
+        _lib.check(lib.vqa_plan_get_info(self._h, C.byref(self.info)))
+        self.N, self.T, self.C = n, t, module_dim
+        self.V = len(arity)
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self._lib.vqa_plan_free(h)
+            self._h = C.c_void_p()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def used_fns(self):
+        out = np.empty((self.N, self.T), dtype=np.float32)
+        _lib.check(self._lib.vqa_plan_used_fns(self._h, out.ctypes.data_as(_lib.f32p)))
+        return out
+
+    def nodes(self):
+        """int32 [num_nodes, 6]: sample, token, column, child0, child1, level."""
+        out = np.empty((self.info.num_nodes, 6), dtype=np.int32)
+        _lib.check(self._lib.vqa_plan_nodes(self._h, out.ctypes.data_as(_lib.i32p)))
+        return out
+
+    def level_nodes(self, level):
+        cnt = self._lib.vqa_plan_level_nodes(self._h, level, None, 0)
+        out = np.empty(max(cnt, 1), dtype=np.int32)
+        self._lib.vqa_plan_level_nodes(self._h, level, out.ctypes.data_as(_lib.i32p), cnt)
+        return out[:cnt]
+
+    def token_counts(self):
+        out = np.empty(self.V, dtype=np.int32)
+        _lib.check(self._lib.vqa_plan_token_counts(self._h, out.ctypes.data_as(_lib.i32p)))
+        return out
+
+    def roots(self):
+        out = np.empty(self.N, dtype=np.int32)
+        _lib.check(self._lib.vqa_plan_roots(self._h, out.ctypes.data_as(_lib.i32p)))
+        return out
+
+    def blob(self):
+        out = np.empty(self.info.blob_words, dtype=np.int32)
+        _lib.check(self._lib.vqa_plan_blob(self._h, out.ctypes.data_as(_lib.i32p)))
+        return out
+
+    def section(self, name):
+        off, cnt = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.vqa_plan_section(self._h, _lib.SEC[name], C.byref(off), C.byref(cnt)))
+        return off.value, cnt.value
+
+    def slot(self, which, index):
+        names = {'F': 0, 'S0': 1, 'Y': 2, 'H': 3, 'dZ': 4, 'dH': 5, 'dF': 6, 'dS0': 7}
+        return self._lib.vqa_plan_slot(self._h, names[which], index)
+
+    def flops(self, feature_dim=(1024, 14, 14), proj_dim=512, fc_dims=(1024,), num_answers=32):
+        """Algorithmic FLOPs (2 per multiply-add) of forward and forward+backward for this
+        batch: stem + parsed tree nodes + classifier; elementwise work is not counted and the
+        input features get no gradient."""
+        hw, c, cin = feature_dim[1] * feature_dim[2], self.C, feature_dim[0]
+        i = self.info
+        f_stem0 = 2 * hw * 9 * cin * c
+        f_stem1 = 2 * hw * 9 * c * c
+        f_u = 36 * hw * c * c
+        f_b = f_u + 4 * hw * c * c
+        prev = c * hw
+        f_cls = 0
+        if proj_dim:
+            f_cls += 2 * hw * c * proj_dim
+            prev = proj_dim * hw
+        for f in fc_dims:
+            f_cls += 2 * prev * f
+            prev = f
+        f_cls += 2 * prev * num_answers
+        fwd = self.N * (f_stem0 + f_stem1 + f_cls) + (i.num_scene + i.num_unary) * f_u + i.num_binary * f_b
+        return fwd, 3 * fwd - self.N * f_stem0
