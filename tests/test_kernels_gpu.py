@@ -1,0 +1,306 @@
+"""Each HIP kernel, called through the C ABI, against a plain fp32 torch computation on the CPU
+of the same op on the same bf16-rounded inputs.  Tolerance: bf16 output rounding (2^-8 relative)
+on top of fp32 accumulation, checked as max abs error <= 1e-2 * max|ref| (stated per test)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+HW = 196
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale)
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def to_slots(x_nchw):
+    """[S, C, 14, 14] fp32 -> bf16 [S, 196, C] device tensor (slot layout)."""
+    s, c = x_nchw.shape[:2]
+    return x_nchw.reshape(s, c, HW).permute(0, 2, 1).contiguous().to(torch.bfloat16).to(dev())
+
+
+def from_slots(t, c):
+    s = t.shape[0]
+    return t.to(torch.float32).cpu().reshape(s, HW, c).permute(0, 2, 1).reshape(s, c, 14, 14)
+
+
+def tiles_tensor(rows):
+    return torch.tensor(rows, dtype=torch.int32).reshape(-1).to(dev())
+
+
+def close(got, ref, tol=1e-2):
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= tol * scale + 1e-6, 'max err %g vs scale %g' % (err, scale)
+
+
+def test_conv3x3_bias_res_relu_grouped():
+    from vqa_amd import ops
+    C, G, S = 128, 3, 7
+    x = bf(rnd((S, C, 14, 14), 1))
+    res = bf(rnd((S, C, 14, 14), 2))
+    w = bf(rnd((G, C, C, 3, 3), 3, 0.05))
+    b = rnd((G, C), 4, 0.1)
+    groups = [0, 2, 1, 1, 0, 2, 2]
+    arena = torch.cat([to_slots(x), to_slots(res), torch.zeros(S, HW, C, dtype=torch.bfloat16, device=dev())])
+    tiles = tiles_tensor([[i, -1, 2 * S + i, -1, S + i, -1, -1, groups[i]] for i in range(S)])
+    wp = ops.pack_conv_weight(w.to(dev()), G, C, C, 9, C * C * 9, C * 9, 9)
+    ops.conv_tiles(arena, arena, wp, tiles, S, taps=9, k_chunks=1, n_out=C, src_slot_stride=HW * C,
+                   dst_slot_stride=HW * C, src_pix_stride=C, dst_pix_stride=C, w_group_stride=9 * C * C,
+                   bias=b.to(dev()), res=arena, relu=True)
+    torch.cuda.synchronize()
+    got = from_slots(arena[2 * S:], C)
+    ref = torch.stack([F.relu(F.conv2d(x[i:i + 1], w[groups[i]], b[groups[i]], padding=1)[0] + res[i]) for i in range(S)])
+    close(got, ref)
+
+
+def test_conv3x3_multichunk_strided_src_wide_out():
+    """stem-like: 256 input channels read from a wider channels-last buffer, 256 outputs."""
+    from vqa_amd import ops
+    Cin, Cout, S = 256, 256, 3
+    x = bf(rnd((S, Cin, 14, 14), 5))
+    w = bf(rnd((1, Cout, Cin, 3, 3), 6, 0.03))
+    b = rnd((1, Cout), 7, 0.1)
+    src = to_slots(x)
+    dst = torch.zeros(S, HW, Cout, dtype=torch.bfloat16, device=dev())
+    tiles = tiles_tensor([[i, -1, i, -1, -1, -1, -1, 0] for i in range(S)])
+    wp = ops.pack_conv_weight(w.to(dev()), 1, Cout, Cin, 9, 0, Cin * 9, 9)
+    ops.conv_tiles(src, dst, wp, tiles, S, taps=9, k_chunks=2, n_out=Cout, src_slot_stride=HW * Cin,
+                   dst_slot_stride=HW * Cout, src_pix_stride=Cin, dst_pix_stride=Cout,
+                   w_group_stride=9 * Cin * Cout, bias=b.to(dev()), relu=True)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(x, w[0], b[0], padding=1))
+    close(from_slots(dst, Cout), ref)
+
+
+def test_conv1x1_pair_sources():
+    """ConcatBlock.proj: 1x1 conv over the channel concatenation of two maps, no cat copy."""
+    from vqa_amd import ops
+    C, S, G = 128, 4, 2
+    x0, x1 = bf(rnd((S, C, 14, 14), 8)), bf(rnd((S, C, 14, 14), 9))
+    w = bf(rnd((G, C, 2 * C, 1, 1), 10, 0.06))
+    b = rnd((G, C), 11, 0.1)
+    arena = torch.cat([to_slots(x0), to_slots(x1), torch.zeros(S, HW, C, dtype=torch.bfloat16, device=dev())])
+    tiles = tiles_tensor([[i, S + i, 2 * S + i, -1, -1, -1, -1, i % G] for i in range(S)])
+    wp = ops.pack_conv_weight(w.to(dev()), G, C, 2 * C, 1, 2 * C * C, 2 * C, 1)
+    ops.conv_tiles(arena, arena, wp, tiles, S, taps=1, k_chunks=2, n_out=C, src_slot_stride=HW * C,
+                   dst_slot_stride=HW * C, src_pix_stride=C, dst_pix_stride=C, w_group_stride=2 * C * C,
+                   bias=b.to(dev()), pair_chunks=1, relu=True)
+    torch.cuda.synchronize()
+    ref = torch.stack([F.relu(F.conv2d(torch.cat([x0[i:i + 1], x1[i:i + 1]], 1), w[i % G], b[i % G]))[0] for i in range(S)])
+    close(from_slots(arena[2 * S:], C), ref)
+
+
+def test_conv_dgrad_with_mask_and_residual():
+    """Input gradient of a 3x3 conv = the same kernel on flipped/transposed weights; epilogue
+    (acc + res) * (mask > 0)."""
+    from vqa_amd import ops
+    C, S = 128, 3
+    dy = bf(rnd((S, C, 14, 14), 12))
+    res = bf(rnd((S, C, 14, 14), 13))
+    act = bf(F.relu(rnd((S, C, 14, 14), 14)))
+    w = bf(rnd((1, C, C, 3, 3), 15, 0.05))
+    arena = torch.cat([to_slots(dy), to_slots(res), to_slots(act), torch.zeros(S, HW, C, dtype=torch.bfloat16, device=dev())])
+    tiles = tiles_tensor([[i, -1, 3 * S + i, -1, S + i, 2 * S + i, -1, 0] for i in range(S)])
+    # dgrad weights: n = original input channel, k = original output channel, taps flipped
+    wd = ops.pack_conv_weight(w.to(dev()), 1, C, C, 9, 0, 9, C * 9, flip=True)
+    ops.conv_tiles(arena, arena, wd, tiles, S, taps=9, k_chunks=1, n_out=C, src_slot_stride=HW * C,
+                   dst_slot_stride=HW * C, src_pix_stride=C, dst_pix_stride=C, w_group_stride=9 * C * C,
+                   res=arena, mask=arena)
+    torch.cuda.synchronize()
+    ref = (F.conv_transpose2d(dy, w[0], padding=1) + res) * (act > 0)
+    close(from_slots(arena[3 * S:], C), ref)
+
+
+def test_conv1x1_dgrad_pair_out():
+    """proj input gradient: 256 outputs split over two destination maps with separate masks."""
+    from vqa_amd import ops
+    C, S = 128, 3
+    dp = bf(rnd((S, C, 14, 14), 16))
+    a0, a1 = bf(F.relu(rnd((S, C, 14, 14), 17))), bf(F.relu(rnd((S, C, 14, 14), 18)))
+    w = bf(rnd((1, C, 2 * C, 1, 1), 19, 0.06))
+    z = torch.zeros(S, HW, C, dtype=torch.bfloat16, device=dev())
+    arena = torch.cat([to_slots(dp), to_slots(a0), to_slots(a1), z, z.clone()])
+    tiles = tiles_tensor([[i, -1, 3 * S + i, 4 * S + i, -1, S + i, 2 * S + i, 0] for i in range(S)])
+    wd = ops.pack_conv_weight(w.to(dev()), 1, 2 * C, C, 1, 0, 1, 2 * C)
+    ops.conv_tiles(arena, arena, wd, tiles, S, taps=1, k_chunks=1, n_out=2 * C, src_slot_stride=HW * C,
+                   dst_slot_stride=HW * C, src_pix_stride=C, dst_pix_stride=C, w_group_stride=2 * C * C,
+                   mask=arena, pair_out=1)
+    torch.cuda.synchronize()
+    full = F.conv_transpose2d(dp, w[0])
+    close(from_slots(arena[3 * S:4 * S], C), full[:, :C] * (a0 > 0))
+    close(from_slots(arena[4 * S:], C), full[:, C:] * (a1 > 0))
+
+
+def _wgrad_ref(x, dy, w_shape, padding):
+    w = torch.zeros(w_shape, requires_grad=True)
+    b = torch.zeros(w_shape[0], requires_grad=True)
+    F.conv2d(x, w, b, padding=padding).backward(dy)
+    return w.grad, b.grad
+
+
+def test_wgrad3x3_grouped_accumulates_over_nodes():
+    from vqa_amd import ops
+    C, S, G = 128, 9, 3
+    x = bf(rnd((S, C, 14, 14), 20))
+    dy = bf(rnd((S, C, 14, 14), 21))
+    arena = torch.cat([to_slots(x), to_slots(dy)])
+    # group 0: nodes 0..3 (two items), group 2: nodes 4..8; group 1 unused
+    items = tiles_tensor([[0, 0, 3, 0], [0, 3, 1, 0], [2, 4, 5, 0]])
+    src_slots = tiles_tensor(list(range(S)))
+    dy_slots = tiles_tensor([S + i for i in range(S)])
+    dw = torch.zeros(G, 9, C, C, device=dev())
+    db = torch.zeros(G, C, device=dev())
+    ops.wgrad_tiles(arena, arena, (items, 0), 3, (src_slots, 0), (dy_slots, 0), dw, db, taps=9, k_chunks=1,
+                    n_out=C, src_slot_stride=HW * C, dy_slot_stride=HW * C, src_pix_stride=C,
+                    dy_pix_stride=C, dw_group_stride=9 * C * C)
+    out = torch.zeros(G, C, C, 3, 3, device=dev())
+    ops.unpack_conv_grad(dw, out, G, C, C, 9, C * C * 9)
+    torch.cuda.synchronize()
+    out, db = out.cpu(), db.cpu()
+    for g, sl in ((0, slice(0, 4)), (2, slice(4, 9))):
+        rw, rb = _wgrad_ref(x[sl], dy[sl], (C, C, 3, 3), 1)
+        close(out[g], rw, 5e-3)
+        close(db[g], rb, 5e-3)
+    assert out[1].abs().max() == 0 and db[1].abs().max() == 0
+
+
+def test_wgrad1x1_pair_sources():
+    from vqa_amd import ops
+    C, S = 128, 5
+    x0, x1 = bf(rnd((S, C, 14, 14), 22)), bf(rnd((S, C, 14, 14), 23))
+    dy = bf(rnd((S, C, 14, 14), 24))
+    arena = torch.cat([to_slots(x0), to_slots(x1), to_slots(dy)])
+    items = tiles_tensor([[0, 0, S, 0]])
+    dw = torch.zeros(1, 1, 2 * C, C, device=dev())
+    db = torch.zeros(1, C, device=dev())
+    ops.wgrad_tiles(arena, arena, (items, 0), 1, (tiles_tensor(list(range(S))), 0),
+                    (tiles_tensor([2 * S + i for i in range(S)]), 0), dw, db, taps=1, k_chunks=2, n_out=C,
+                    src_slot_stride=HW * C, dy_slot_stride=HW * C, src_pix_stride=C, dy_pix_stride=C,
+                    dw_group_stride=2 * C * C, src1_slots=(tiles_tensor([S + i for i in range(S)]), 0),
+                    pair_chunks=1)
+    out = torch.zeros(1, C, 2 * C, 1, 1, device=dev())
+    ops.unpack_conv_grad(dw, out, 1, C, 2 * C, 1, 2 * C * C)
+    torch.cuda.synchronize()
+    rw, rb = _wgrad_ref(torch.cat([x0, x1], 1), dy, (C, 2 * C, 1, 1), 0)
+    close(out[0].cpu(), rw, 5e-3)
+    close(db[0].cpu(), rb, 5e-3)
+
+
+def _padded(t, rows, cols):
+    out = torch.zeros(rows, cols, dtype=torch.bfloat16)
+    out[:t.shape[0], :t.shape[1]] = t.to(torch.bfloat16)
+    return out.to(dev())
+
+
+@pytest.mark.parametrize('M,N,K,split', [(128, 128, 64, 1), (200, 136, 320, 1), (70, 300, 1024, 4), (5, 32, 128, 2)])
+def test_gemm_nt(M, N, K, split):
+    from vqa_amd import ops
+    a, b = bf(rnd((M, K), 30)), bf(rnd((N, K), 31))
+    Mp, Np = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    ldc = (N + 3) // 4 * 4
+    c = torch.full((split, M, ldc), 7.0, device=dev())
+    ops.gemm(_padded(a, Mp, K), _padded(b, Np, K), c, M, N, K, lda=K, ldb=K, ldc=ldc, split_k=split)
+    torch.cuda.synchronize()
+    close(c.sum(0).cpu()[:, :N], a @ b.t(), 2e-3)
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (100, 264, 192)])
+def test_gemm_nn_bf16_mask(M, N, K):
+    from vqa_amd import ops
+    a, b = bf(rnd((M, K), 32)), bf(rnd((K, N), 33))
+    mk = bf(F.relu(rnd((M, N), 34)))
+    Mp, Np = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    c = torch.zeros(M, Np, dtype=torch.bfloat16, device=dev())
+    ops.gemm(_padded(a, Mp, K), _padded(b, K, Np), c, M, N, K, lda=K, ldb=Np, ldc=Np, b_kmajor=True,
+             out_bf16=True, mask=_padded(mk, M, Np))
+    torch.cuda.synchronize()
+    close(c.to(torch.float32).cpu()[:, :N], (a @ b) * (mk > 0))
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (40, 392, 256)])
+def test_gemm_tn(M, N, K):
+    from vqa_amd import ops
+    a, b = bf(rnd((K, M), 35)), bf(rnd((K, N), 36))
+    Mp, Np = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    c = torch.zeros(M, N, device=dev())
+    ops.gemm(_padded(a, K, Mp), _padded(b, K, Np), c, M, N, K, lda=Mp, ldb=Np, ldc=N, a_kmajor=True, b_kmajor=True)
+    torch.cuda.synchronize()
+    close(c.cpu(), a.t() @ b, 2e-3)
+
+
+def test_layout_helpers():
+    from vqa_amd import ops
+    n, cin, cpad = 3, 100, 128
+    x = rnd((n, cin, 14, 14), 40)
+    out = torch.full((n, HW, cpad), 9.0, dtype=torch.bfloat16, device=dev())
+    ops.nchw_to_nhwc(x.to(dev()), out, n, cin, cpad)
+    back = torch.zeros(n, cpad, HW, device=dev())
+    ops.nhwc_to_nchw(out, back, n, cpad)
+    torch.cuda.synchronize()
+    ref = torch.zeros(n, cpad, HW)
+    ref[:, :cin] = bf(x).reshape(n, cin, HW)
+    assert torch.equal(out.to(torch.float32).cpu(), ref.permute(0, 2, 1))
+    assert torch.equal(back.cpu(), ref)
+    # FC weight permutation and its inverse on gradients
+    f, p = 5, 64
+    w = rnd((f, p * HW), 41)
+    wn = torch.zeros(128, HW * p, dtype=torch.bfloat16, device=dev())
+    ops.fc_weight_to_nhwc(w.to(dev()), wn, f, 128, p)
+    g = torch.zeros(f, p * HW, device=dev())
+    gin = rnd((f, HW * p), 42)
+    ops.fc_grad_from_nhwc(gin.to(dev()), g, f, p)
+    torch.cuda.synchronize()
+    assert torch.equal(wn[:f].to(torch.float32).cpu(), bf(w).reshape(f, p, HW).permute(0, 2, 1).reshape(f, -1))
+    assert torch.equal(g.cpu(), gin.reshape(f, HW, p).permute(0, 2, 1).reshape(f, -1))
+
+
+def test_bias_act_colsum_castpad():
+    from vqa_amd import ops
+    rows, cols = 37, 100
+    acc = rnd((3, rows, 104), 43)
+    bias = rnd((cols,), 44)
+    out = torch.zeros(rows, 128, dtype=torch.bfloat16, device=dev())
+    ops.bias_act(acc.to(dev()), bias.to(dev()), out, rows, cols, 104, 128, True, slabs=3, slab_stride=rows * 104)
+    outf = torch.zeros(rows, cols, device=dev())
+    ops.bias_act(acc.to(dev()), bias.to(dev()), outf, rows, cols, 104, cols, False, slabs=3, slab_stride=rows * 104)
+    cs = torch.zeros(cols, device=dev())
+    ops.col_sum(outf, cs, rows, cols, cols)
+    cb = torch.zeros(cols, device=dev())
+    ops.col_sum(out, cb, rows, cols, 128)
+    cp = torch.full((128, 128), 3.0, dtype=torch.bfloat16, device=dev())
+    ops.cast_pad(outf, cp, rows, cols, 128, 128)
+    torch.cuda.synchronize()
+    ref = acc[:, :, :cols].sum(0) + bias
+    close(out[:, :cols].to(torch.float32).cpu(), F.relu(ref))
+    close(outf.cpu(), ref, 1e-5)
+    close(cs.cpu(), ref.sum(0), 1e-4)
+    close(cb.cpu(), bf(F.relu(ref)).sum(0), 1e-2)
+    want = torch.zeros(128, 128)
+    want[:rows, :cols] = bf(outf.cpu())
+    assert torch.equal(cp.to(torch.float32).cpu(), want)
+
+
+def test_slot_sum_mask():
+    from vqa_amd import ops
+    C, S = 128, 6
+    x = bf(rnd((S, HW, C), 45))
+    mk = bf(F.relu(rnd((2, HW, C), 46)))
+    arena = torch.cat([x, mk, torch.zeros(2, HW, C)]).to(torch.bfloat16).to(dev())
+    blob = tiles_tensor([0, 2, 6] + [0, 3, 1, 2, 4, 5] + [S + 2, S + 3] + [S, S + 1])
+    ops.slot_sum_mask(arena, blob, 0, 3, 9, 11, 2, HW * C)
+    torch.cuda.synchronize()
+    got = arena[S + 2:].to(torch.float32).cpu()
+    close(got[0], (x[0] + x[3]) * (mk[0] > 0))
+    close(got[1], (x[1] + x[2] + x[4] + x[5]) * (mk[1] > 0))

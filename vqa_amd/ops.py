@@ -1,0 +1,133 @@
+"""Thin torch-tensor front ends of the C-ABI device entry points.
+
+torch is plumbing here: it owns device memory and the current HIP stream; every computation
+below is a hand-written gfx950 kernel inside libvqa_amd.so.  Nothing falls back to torch ops.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+HW = 196
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('vqa_amd device op called with a CPU tensor: the HIP path has no '
+                               'CPU fallback')
+
+
+def conv_tiles(src, dst, w_packed, tiles, num_tiles, *, taps, k_chunks, n_out, src_slot_stride,
+               dst_slot_stride, src_pix_stride, dst_pix_stride, w_group_stride, bias=None,
+               res=None, mask=None, pair_chunks=0, pair_out=0, relu=False, tiles_offset=0):
+    """tiles: int32 device tensor holding vqa_conv_tile records from word `tiles_offset`."""
+    _need_cuda(src, dst, w_packed, tiles)
+    p = _lib.ConvParams()
+    p.src, p.dst = src.data_ptr(), dst.data_ptr()
+    p.res = res.data_ptr() if res is not None else dst.data_ptr()
+    p.mask = mask.data_ptr() if mask is not None else dst.data_ptr()
+    p.w = w_packed.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else 0
+    p.tiles = tiles.data_ptr() + 4 * tiles_offset
+    p.src_slot_stride, p.dst_slot_stride, p.w_group_stride = src_slot_stride, dst_slot_stride, w_group_stride
+    p.src_pix_stride, p.dst_pix_stride = src_pix_stride, dst_pix_stride
+    p.k_chunks, p.n_out, p.pair_chunks, p.pair_out = k_chunks, n_out, pair_chunks, pair_out
+    p.flags = (_lib.CONV_BIAS if bias is not None else 0) | (_lib.CONV_RELU if relu else 0)
+    p.num_tiles = num_tiles
+    _lib.check(_lib.load().vqa_conv_tiles(C.byref(p), taps, _stream()))
+
+
+def pack_conv_weight(w, groups, n_out, k_in, taps, g_stride, n_stride, k_stride, flip=False, out=None):
+    """fp32 weights -> bf16 slabs [group][chunk][tap][half][n][64] (swizzled LDS image)."""
+    _need_cuda(w)
+    kpad = (k_in + 127) // 128 * 128
+    if out is None:
+        out = torch.empty(groups * kpad * taps * n_out, dtype=torch.bfloat16, device=w.device)
+    assert out.numel() == groups * kpad * taps * n_out and w.dtype == torch.float32
+    _lib.check(_lib.load().vqa_pack_conv_weight(_ptr(w), _ptr(out), groups, n_out, k_in, taps,
+                                                g_stride, n_stride, k_stride, int(flip), _stream()))
+    return out
+
+
+def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps, k_chunks, n_out,
+                src_slot_stride, dy_slot_stride, src_pix_stride, dy_pix_stride, dw_group_stride,
+                src1_slots=None, pair_chunks=0):
+    """items / *_slots are (tensor, word_offset) pairs into an int32 device blob."""
+    p = _lib.WgradParams()
+    p.src, p.dy = src.data_ptr(), dy.data_ptr()
+    p.items = items[0].data_ptr() + 4 * items[1]
+    p.src_slots = src_slots[0].data_ptr() + 4 * src_slots[1]
+    p.src1_slots = (src1_slots[0].data_ptr() + 4 * src1_slots[1]) if src1_slots is not None else 0
+    p.dy_slots = dy_slots[0].data_ptr() + 4 * dy_slots[1]
+    p.dw = dw.data_ptr()
+    p.db = db.data_ptr() if db is not None else 0
+    p.src_slot_stride, p.dy_slot_stride, p.dw_group_stride = src_slot_stride, dy_slot_stride, dw_group_stride
+    p.src_pix_stride, p.dy_pix_stride = src_pix_stride, dy_pix_stride
+    p.k_chunks, p.pair_chunks, p.n_out, p.num_items = k_chunks, pair_chunks, n_out, num_items
+    _lib.check(_lib.load().vqa_wgrad_tiles(C.byref(p), taps, _stream()))
+
+
+def unpack_conv_grad(dw, out, groups, n_out, k_in, taps, out_g_stride):
+    _lib.check(_lib.load().vqa_unpack_conv_grad(_ptr(dw), _ptr(out), groups, n_out, k_in, taps,
+                                                out_g_stride, _stream()))
+
+
+def gemm(a, b, c, M, N, K, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, out_bf16=False,
+         split_k=1, mask=None):
+    _need_cuda(a, b, c)
+    p = _lib.GemmParams()
+    p.a, p.b, p.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    p.mask = mask.data_ptr() if mask is not None else 0
+    p.lda, p.ldb, p.ldc, p.M, p.N, p.K = lda, ldb, ldc, M, N, K
+    p.a_kmajor, p.b_kmajor = int(a_kmajor), int(b_kmajor)
+    p.out_mode, p.split_k = (2 if out_bf16 else 1), split_k
+    _lib.check(_lib.load().vqa_gemm(C.byref(p), _stream()))
+
+
+def nchw_to_nhwc(x, out, n, cin, cpad):
+    _need_cuda(x, out)
+    _lib.check(_lib.load().vqa_nchw_to_nhwc(_ptr(x), _ptr(out), n, cin, cpad, _stream()))
+
+
+def nhwc_to_nchw(x, out, n, c):
+    _lib.check(_lib.load().vqa_nhwc_to_nchw(_ptr(x), _ptr(out), n, c, _stream()))
+
+
+def cast_pad(w, out, rows, cols, rows_pad, cols_pad):
+    _lib.check(_lib.load().vqa_cast_pad(_ptr(w), _ptr(out), rows, cols, rows_pad, cols_pad, _stream()))
+
+
+def fc_weight_to_nhwc(w, out, f, fpad, p):
+    _lib.check(_lib.load().vqa_fc_weight_to_nhwc(_ptr(w), _ptr(out), f, fpad, p, _stream()))
+
+
+def fc_grad_from_nhwc(g, out, f, p):
+    _lib.check(_lib.load().vqa_fc_grad_from_nhwc(_ptr(g), _ptr(out), f, p, _stream()))
+
+
+def bias_act(acc, bias, out, rows, cols, ld_acc, ld_out, relu, slabs=1, slab_stride=0):
+    _lib.check(_lib.load().vqa_bias_act(_ptr(acc), _ptr(bias), _ptr(out), rows, cols, ld_acc, ld_out,
+                                        int(relu), slabs, slab_stride,
+                                        int(out.dtype == torch.float32), _stream()))
+
+
+def col_sum(x, out, rows, cols, ld):
+    _lib.check(_lib.load().vqa_col_sum(_ptr(x), _ptr(out), rows, cols, ld,
+                                       int(x.dtype == torch.bfloat16), _stream()))
+
+
+def slot_sum_mask(arena, blob, off_offsets, off_src, off_dst, off_mask, n_dst, slot_elems):
+    b = blob.data_ptr()
+    _lib.check(_lib.load().vqa_slot_sum_mask(_ptr(arena), C.c_void_p(b + 4 * off_offsets),
+                                             C.c_void_p(b + 4 * off_src), C.c_void_p(b + 4 * off_dst),
+                                             C.c_void_p(b + 4 * off_mask), n_dst, slot_elems, _stream()))
