@@ -1,0 +1,56 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every declared symbol,
+the drop-in module keeps the reference's constructor / state-dict surface, and it refuses to run
+without the HIP path."""
+import os
+import re
+
+import pytest
+import torch
+
+from vqa_amd import _lib, synth
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(os.path.dirname(_lib._HERE), 'include', 'vqa_amd.h')).read()
+    declared = set(re.findall(r'\b(vqa_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations found'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.vqa_version() >= 100
+
+
+def test_state_dict_keys_match_reference_order(vocab):
+    from vqa_amd.module_net import ModuleNet
+    net = ModuleNet(False, vocab)
+    want = synth.state_dict_shapes(vocab)          # asserted equal to the reference in make_golden.py
+    got = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert got == [(k, tuple(s)) for k, s in want]
+    assert sum(p.numel() for p in net.parameters()) == 117471136
+    net.load_state_dict({k: torch.zeros(s) for k, s in want})
+    # reference kwargs round trip (Functions.py:107-119)
+    ModuleNet(False, vocab=vocab, feature_dim=(1024, 14, 14), stem_batchnorm=False, stem_num_layers=2,
+              module_dim=128, module_residual=True, module_batchnorm=False, classifier_proj_dim=512,
+              classifier_downsample='maxpool2', classifier_fc_layers=(1024,), classifier_batchnorm=False,
+              classifier_dropout=0)
+
+
+def test_unsupported_options_refuse(vocab):
+    from vqa_amd.module_net import ModuleNet
+    for kw in (dict(module_batchnorm=True), dict(stem_batchnorm=True), dict(classifier_batchnorm=True),
+               dict(module_residual=False), dict(classifier_dropout=0.5), dict(classifier_downsample='maxpool4'),
+               dict(module_dim=100), dict(feature_dim=(1024, 7, 7))):
+        with pytest.raises(NotImplementedError):
+            ModuleNet(False, vocab, **kw)
+
+
+def test_no_cpu_fallback(vocab):
+    from vqa_amd.module_net import ModuleNet
+    net = ModuleNet(False, vocab, feature_dim=(128, 14, 14), classifier_proj_dim=128, classifier_fc_layers=(128,))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net(torch.zeros(1, 128, 14, 14), torch.zeros(1, 4, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 128, 14, 14), torch.zeros(1, 4, 2, dtype=torch.int64))
+    with pytest.raises(AttributeError):
+        net(torch.zeros(1, 128, 14, 14), [[{'function': 'scene', 'inputs': [], 'value_inputs': []}]])

@@ -1,0 +1,192 @@
+"""End-to-end parity of the HIP executor (through the C ABI) with the CPU oracle and with the golden
+vectors captured from the reference.
+
+Tolerance (BASELINE north star): bf16 path, logits and gradients within 2e-2 relative error, where
+relative error of a tensor is ||got - ref||_2 / ||ref||_2; used_fns and schedule bit-exact.
+
+Logits are compared with the fp32 oracle.  Gradients are compared with the oracle run with bf16
+storage points (same algorithm and fp32 arithmetic; values and back-flowing gradients rounded to
+bf16 where a bf16 executor stores them), the same upstream d(loss)/d(logits), and the oracle's
+stored activations forced to the ones the HIP forward saved, i.e. the exact vector-Jacobian
+product at the HIP path's own forward.  Without the forcing no two bf16 executors can be compared
+at 2e-2: a ReLU whose pre-activation lies within rounding noise of zero flips its mask, a fraction
+f of flipped units moves a gradient by about sqrt(f) whatever the arithmetic, and the flips
+compound with depth (measured here: 1-ulp differences in <1 % of a layer's outputs grow to 10-25 %
+gradient differences after 13 modules; the CPU oracle with bf16 storage sits just as far from the
+fp32 oracle).  The unforced comparisons are kept below as loose sanity bounds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.module_net_ref import ModuleNetRef
+from oracle.make_golden_util import sample_slice
+from vqa_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-2
+
+
+def rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+def run_pair(vocab, dims, prog, x, ans, seed):
+    from vqa_amd.module_net import ModuleNet
+    sd = synth.synth_state_dict(seed, vocab, **dims)
+    xt, pt, at = torch.from_numpy(x), torch.from_numpy(prog), torch.from_numpy(ans)
+    with torch.no_grad():
+        l32 = ModuleNetRef(vocab, sd)(xt, pt)                     # fp32 oracle logits
+    up = _ce_grad(l32, at)                                        # Train_model.py:312
+    net = ModuleNet(False, vocab, **dims)
+    net.load_state_dict(sd)
+    net.cuda().train()
+    net.keep_state = True
+    logits = net(xt.cuda(), pt.cuda())
+    logits.backward(up.cuda())                                    # identical upstream gradient
+    torch.cuda.synchronize()
+    st = net.last_state
+    ref = ModuleNetRef(vocab, sd, storage='bf16', forced=lambda kind, i=0: net.stored_activation(st, kind, i))
+    ref(xt, pt).backward(up)
+    return net, logits, ref, l32
+
+
+def check_pair(net, logits, ref, l32):
+    assert rel(logits, l32) <= TOL, 'logits rel err %g' % rel(logits, l32)
+    assert torch.equal(net.used_fns.cpu(), ref.used_fns)
+    assert net.used_fns.is_cuda and net.used_fns.dtype == torch.float32
+    rg = ref.grads()
+    worst = ('', 0.0)
+    for k, p in net.named_parameters():
+        if rg[k] is None:
+            assert p.grad is None, '%s: token unused in the batch must keep grad None' % k
+            continue
+        assert p.grad is not None, k
+        e = rel(p.grad, rg[k])
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] <= TOL, 'gradient rel err %g on %s' % (worst[1], worst[0])
+
+
+def _ce_grad(logits, ans):
+    lg = logits.clone().requires_grad_(True)
+    F.cross_entropy(lg, ans).backward()
+    return lg.grad
+
+
+def small_dims(cin=96):
+    return dict(feature_dim=(cin, 14, 14), module_dim=128, classifier_proj_dim=128,
+                classifier_fc_layers=(128,))
+
+
+def test_small_model_quirk_rows(vocab):
+    """Every interpreter quirk in one batch: all-NULL, <START>, <UNK>, missing inputs, trailing
+    tokens; input channels not a multiple of 128; batch not a multiple of 64."""
+    t2i = vocab['program_token_to_idx']
+    T = 12
+    sc, cnt, un, eq, fl = t2i['scene'], t2i['count'], t2i['union'], t2i['equal_color'], t2i['filter_color[red]']
+
+    def pad(r):
+        return (r + [0] * T)[:T]
+    rows = [pad([]), pad([1, cnt, fl, sc, 2]), pad([cnt, 3, fl, sc, 2]), [un] * T,
+            pad([sc, cnt, fl, un, 2]), pad([eq, cnt, fl, sc, cnt, fl, sc, 2]), pad([0] * (T - 2) + [un, sc]),
+            pad([un, eq, sc, sc, un, sc, fl, sc, 2]), pad([2])]
+    prog = np.concatenate([np.array(rows, dtype=np.int64), synth.synth_programs(3, 4, vocab, max_len=T, max_nodes=9)])
+    n = prog.shape[0]
+    dims = small_dims()
+    x = synth.synth_features(5, n, dims['feature_dim'])
+    ans = synth.synth_answers(5, n)
+    check_pair(*run_pair(vocab, dims, prog, x, ans, 7))
+
+
+def test_small_model_sampler_programs_batch_70(vocab):
+    dims = small_dims(128)
+    prog = synth.synth_sampler_programs(8, 70, 44, 16)
+    x = synth.synth_features(9, 70, dims['feature_dim'])
+    ans = synth.synth_answers(9, 70)
+    check_pair(*run_pair(vocab, dims, prog, x, ans, 11))
+
+
+def test_second_step_and_eval_forward_between(vocab):
+    """A no-grad forward between a training forward and its backward must not disturb it, and a
+    weight update must be picked up by the next forward (packed copies refresh)."""
+    from vqa_amd.module_net import ModuleNet
+    dims = small_dims(128)
+    sd = synth.synth_state_dict(2, vocab, **dims)
+    prog = synth.synth_programs(4, 6, vocab, max_len=10, max_nodes=8)
+    x = synth.synth_features(4, 6, dims['feature_dim'])
+    ans = torch.from_numpy(synth.synth_answers(4, 6))
+    net = ModuleNet(False, vocab, **dims)
+    net.load_state_dict(sd)
+    net.cuda()
+    net.keep_state = True
+    xg, pg = torch.from_numpy(x).cuda(), torch.from_numpy(prog).cuda()
+    logits = net(xg, pg)
+    st = net.last_state
+    with torch.no_grad():
+        other = net(xg[:2].expand(2, -1, -1, -1).contiguous(), pg[2:4])
+    assert other.shape == (2, 32) and not other.requires_grad
+    F.cross_entropy(logits, ans.cuda()).backward()
+    g1 = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    ref = ModuleNetRef(vocab, sd, storage='bf16', forced=lambda kind, i=0: net.stored_activation(st, kind, i))
+    rl = ref(torch.from_numpy(x), torch.from_numpy(prog))
+    rl.backward(_ce_grad(logits.detach().cpu(), ans))
+    for k, g in g1.items():
+        assert rel(g, ref.grads()[k]) <= TOL, k
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+    l2 = net(xg, pg)
+    ref2 = ModuleNetRef(vocab, {k: v * 0.5 for k, v in sd.items()})
+    assert rel(l2, ref2(torch.from_numpy(x), torch.from_numpy(prog))) <= TOL
+
+
+def test_full_default_against_reference_golden(vocab, golden_dir):
+    """Default 117 M-parameter network.  Logits against vectors captured from the reference
+    executor itself; gradients against the bf16-storage oracle at 2e-2, and against the reference's
+    fp32 gradients at the loose bound that bf16 mask flips allow."""
+    from vqa_amd.module_net import ModuleNet
+    d = np.load(os.path.join(golden_dir, 'full_default.npz'))
+    seed, prog = int(d['seed']), d['program']
+    n = prog.shape[0]
+    x = synth.synth_features(seed, n)
+    sd = synth.synth_state_dict(seed, vocab)
+    net = ModuleNet(False, vocab)
+    assert sum(p.numel() for p in net.parameters()) == 117471136
+    net.load_state_dict(sd)
+    net.cuda().train()
+    net.keep_state = True
+    logits = net(torch.from_numpy(x).cuda(), torch.from_numpy(prog).cuda())
+    up = _ce_grad(torch.from_numpy(d['logits']), torch.from_numpy(d['answers']))   # reference's own dlogits
+    logits.backward(up.cuda())
+    torch.cuda.synchronize()
+    assert rel(logits, torch.from_numpy(d['logits'])) <= TOL
+    np.testing.assert_array_equal(net.used_fns.cpu().numpy(), d['used_fns'])
+    st = net.last_state
+    ref = ModuleNetRef(vocab, sd, storage='bf16', forced=lambda kind, i=0: net.stored_activation(st, kind, i))
+    ref(torch.from_numpy(x), torch.from_numpy(prog)).backward(up)
+    rg = ref.grads()
+    for k, p in net.named_parameters():
+        if ('gnorm/' + k) not in d.files:
+            assert p.grad is None and rg[k] is None, k
+            continue
+        assert rel(p.grad, rg[k]) <= TOL, '%s %g' % (k, rel(p.grad, rg[k]))
+        gn = float(d['gnorm/' + k])
+        assert abs(p.grad.double().norm().item() - gn) <= 0.5 * gn, k      # vs fp32 reference: mask flips
+
+
+def test_errors_on_gpu_module(vocab):
+    from vqa_amd.module_net import ModuleNet
+    net = ModuleNet(False, vocab, **small_dims(128)).cuda()
+    x = torch.zeros(2, 128, 14, 14, device='cuda')
+    with pytest.raises(AssertionError):
+        net(x, torch.zeros(3, 5, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        net(x, torch.zeros(2, dtype=torch.int64))
+    with pytest.raises(KeyError):
+        net(x, torch.full((2, 5), 44, dtype=torch.int64))
+    with pytest.raises(RuntimeError):
+        net(x.cpu(), torch.zeros(2, 5, dtype=torch.int64))

@@ -1,0 +1,462 @@
+"""`ModuleNet`: drop-in for the reference execution engine (`Module_Model.py:95-248`).
+
+Same constructor, same `forward(x, program) -> logits [N, num_answers]`, same `used_fns`, same
+state-dict keys; the body is the MI355X path: native scheduler + grouped HIP kernels behind the
+C ABI of libvqa_amd.so.  Submodules below only hold parameters under the reference's names
+(`stem.0.weight`, `<token>.conv1.weight`, `<token>.proj.weight`, `classifier.3.weight`, ...);
+they are never called.  There is no CPU or eager-torch fallback: a CPU tensor or a missing
+library raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, ops, vocab as V
+from .schedule import Plan
+
+HW = 196
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class _ResidualBlockParams(nn.Module):
+    """Parameter holder named like `Layers.ResidualBlock` (`Layers.py:11-27`)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv1 = nn.Conv2d(dim, dim, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv2d(dim, dim, kernel_size=3, padding=1)
+
+
+class _ConcatBlockParams(nn.Module):
+    """Parameter holder named like `ConcatBlock` (`Module_Model.py:15-35`)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(2 * dim, dim, kernel_size=1, padding=0)
+        self.conv1 = nn.Conv2d(dim, dim, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv2d(dim, dim, kernel_size=3, padding=1)
+
+
+class _Flatten(nn.Module):
+    pass
+
+
+class _Workspace:
+    """The caller-owned device buffers of the C ABI.  Every call gets fresh tensors from torch's
+    caching allocator, so a forward whose backward is still pending is never overwritten by
+    another forward (MAPO scoring runs eval forwards between a train forward and its backward,
+    Train_model.py:339-369)."""
+
+    def get(self, name, numel, dtype, device, zero=False):
+        return (torch.zeros if zero else torch.empty)(numel, dtype=dtype, device=device)
+
+
+class _ExecFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, plan, need_grad, *params):
+        ctx.net = net
+        ctx.state = net._run_forward(x, plan, need_grad)
+        return ctx.state['logits']
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        grads = ctx.net._run_backward(ctx.state, dlogits)
+        return (None, None, None, None) + tuple(grads)
+
+
+class ModuleNet(nn.Module):
+    def __init__(self, info, vocab,
+                 feature_dim=(1024, 14, 14),
+                 stem_num_layers=2,
+                 stem_batchnorm=False,
+                 module_dim=128,
+                 module_residual=True,
+                 module_batchnorm=False,
+                 classifier_proj_dim=512,
+                 classifier_downsample='maxpool2',
+                 classifier_fc_layers=(1024,),
+                 classifier_batchnorm=False,
+                 classifier_dropout=0):
+        super().__init__()
+        # Options outside the reference's defaults that would need other kernels: refuse, never
+        # silently differ.
+        if stem_batchnorm or module_batchnorm or classifier_batchnorm:
+            raise NotImplementedError('batch-norm variants are not built for the HIP path')
+        if not module_residual:
+            raise NotImplementedError('module_residual=False is not built for the HIP path')
+        if classifier_dropout:
+            raise NotImplementedError('classifier dropout is not built for the HIP path')
+        if classifier_downsample in ('maxpool12', 'maxpool4'):
+            # only these two strings pool in the reference (Module_Model.py:77-82); its default
+            # 'maxpool2' matches neither, so the default network has no pooling
+            raise NotImplementedError('pooled classifier is not built for the HIP path')
+        if stem_num_layers != 2:
+            raise NotImplementedError('stem_num_layers must be 2 for the HIP path')
+        if tuple(feature_dim[1:]) != (14, 14):
+            raise NotImplementedError('feature maps must be 14 x 14')
+        if module_dim % 128 or not classifier_proj_dim or classifier_proj_dim % 128:
+            raise NotImplementedError('module_dim and classifier_proj_dim must be multiples of 128')
+        if any(f % 128 for f in classifier_fc_layers) or not len(classifier_fc_layers):
+            raise NotImplementedError('classifier_fc_layers must be non-empty multiples of 128')
+
+        cin, c, p = feature_dim[0], module_dim, classifier_proj_dim
+        self.stem = nn.Sequential(nn.Conv2d(cin, c, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(c, c, kernel_size=3, padding=1), nn.ReLU(inplace=True))
+        if info:
+            print('Here is my stem:')
+            print(self.stem)
+        num_answers = len(vocab['answer_idx_to_token'])
+        layers = [nn.Conv2d(c, p, kernel_size=1), nn.ReLU(inplace=True), _Flatten()]
+        prev = p * HW
+        for f in classifier_fc_layers:
+            layers += [nn.Linear(prev, f), nn.ReLU(inplace=True)]
+            prev = f
+        layers.append(nn.Linear(prev, num_answers))
+        self.classifier = nn.Sequential(*layers)
+        if info:
+            print('Here is my classifier:')
+            print(self.classifier)
+
+        self.stem_times = []
+        self.module_times = []
+        self.classifier_times = []
+        self.timing = False
+        self.function_modules_num_inputs = {}
+        self.vocab = vocab
+        for fn_str in vocab['program_token_to_idx']:
+            num_inputs = V.get_num_inputs(fn_str)
+            self.function_modules_num_inputs[fn_str] = num_inputs
+            if fn_str == 'scene' or num_inputs == 1:
+                mod = _ResidualBlockParams(c)
+            else:
+                mod = _ConcatBlockParams(c)
+            self.add_module(fn_str, mod)
+        self.save_module_outputs = False
+
+        self._dims = dict(cin=cin, cin_pad=_rup(cin, 128), c=c, p=p, fcs=tuple(classifier_fc_layers),
+                          na=num_answers, na_pad=_rup(num_answers, 128))
+        i2t = vocab['program_idx_to_token']
+        self._tokens = [i2t[i] for i in range(len(i2t))]
+        self._binary = [V.get_num_inputs(t) == 2 for t in self._tokens]
+        self._fc_idx = [i for i, m in enumerate(self.classifier) if isinstance(m, nn.Linear)]
+        self._ws = _Workspace()
+        self._packed_key = None
+        self._packed = {}
+        self.used_fns = None
+        self.wgrad_chunk = 16
+        self.grad_ready_hook = None   # set by the data-parallel wrapper
+        self.keep_state = False       # tests: keep the last call's buffers in self.last_state
+        self.last_state = None
+
+    # ------------------------------------------------------------------ parameters
+    def _param_groups(self):
+        """Ordered (name, parameter) list handed to the autograd function."""
+        out = [('stem.0', self.stem[0]), ('stem.2', self.stem[2]), ('classifier.0', self.classifier[0])]
+        out += [('classifier.%d' % i, self.classifier[i]) for i in self._fc_idx]
+        plist = []
+        for name, m in out:
+            plist += [(name + '.weight', m.weight), (name + '.bias', m.bias)]
+        for tok in self._tokens:
+            m = self._modules[tok]
+            if isinstance(m, _ConcatBlockParams):
+                plist += [(tok + '.proj.weight', m.proj.weight), (tok + '.proj.bias', m.proj.bias)]
+            plist += [(tok + '.conv1.weight', m.conv1.weight), (tok + '.conv1.bias', m.conv1.bias),
+                      (tok + '.conv2.weight', m.conv2.weight), (tok + '.conv2.bias', m.conv2.bias)]
+        return plist
+
+    def _pack_weights(self, device):
+        """bf16 LDS-image copies of all weights; redone only when a parameter changed."""
+        plist = self._param_groups()
+        key = tuple((p.data_ptr(), p._version) for _, p in plist) + (str(device),)
+        if key == self._packed_key:
+            return self._packed
+        d = self._dims
+        c, p_, cin, cpad = d['c'], d['p'], d['cin'], d['cin_pad']
+        nv = len(self._tokens)
+        pk = {}
+        with torch.no_grad():
+            f32 = dict(dtype=torch.float32, device=device)
+            # module weights gathered per kind into [V, ...] stacks (one weight group per token)
+            w1 = torch.stack([self._modules[t].conv1.weight for t in self._tokens]).to(**f32).contiguous()
+            w2 = torch.stack([self._modules[t].conv2.weight for t in self._tokens]).to(**f32).contiguous()
+            pk['b_conv1'] = torch.stack([self._modules[t].conv1.bias for t in self._tokens]).to(**f32).contiguous()
+            pk['b_conv2'] = torch.stack([self._modules[t].conv2.bias for t in self._tokens]).to(**f32).contiguous()
+            wp = torch.zeros(nv, c, 2 * c, **f32)
+            bp = torch.zeros(nv, c, **f32)
+            for i, t in enumerate(self._tokens):
+                if self._binary[i]:
+                    wp[i] = self._modules[t].proj.weight.reshape(c, 2 * c)
+                    bp[i] = self._modules[t].proj.bias
+            pk['b_proj'] = bp
+            g33 = c * c * 9
+            pk['w_conv1'] = ops.pack_conv_weight(w1, nv, c, c, 9, g33, c * 9, 9)
+            pk['w_conv2'] = ops.pack_conv_weight(w2, nv, c, c, 9, g33, c * 9, 9)
+            pk['wd_conv1'] = ops.pack_conv_weight(w1, nv, c, c, 9, g33, 9, c * 9, flip=True)
+            pk['wd_conv2'] = ops.pack_conv_weight(w2, nv, c, c, 9, g33, 9, c * 9, flip=True)
+            pk['w_proj'] = ops.pack_conv_weight(wp, nv, c, 2 * c, 1, 2 * c * c, 2 * c, 1)
+            pk['wd_proj'] = ops.pack_conv_weight(wp, nv, 2 * c, c, 1, 2 * c * c, 1, 2 * c)
+            s0, s1, cl = self.stem[0], self.stem[2], self.classifier[0]
+            pk['w_stem0'] = ops.pack_conv_weight(s0.weight.contiguous(), 1, c, cin, 9, 0, cin * 9, 9)
+            pk['w_stem1'] = ops.pack_conv_weight(s1.weight.contiguous(), 1, c, c, 9, 0, c * 9, 9)
+            pk['wd_stem1'] = ops.pack_conv_weight(s1.weight.contiguous(), 1, c, c, 9, 0, 9, c * 9, flip=True)
+            pk['w_cls'] = ops.pack_conv_weight(cl.weight.contiguous(), 1, p_, c, 1, 0, c, 1)
+            pk['wd_cls'] = ops.pack_conv_weight(cl.weight.contiguous(), 1, c, p_, 1, 0, 1, c)
+            pk['b_stem0'], pk['b_stem1'], pk['b_cls'] = s0.bias, s1.bias, cl.bias
+            # linear layers: bf16 [out padded to 128][in]; the first one over the flattened map is
+            # re-ordered from c*196+hw (Layers.py:42-44) to the channels-last hw*P+c
+            fcw = []
+            for li, idx in enumerate(self._fc_idx):
+                lin = self.classifier[idx]
+                fo, fi = lin.weight.shape
+                buf = torch.zeros(_rup(fo, 128), fi, dtype=torch.bfloat16, device=device)
+                if li == 0:
+                    ops.fc_weight_to_nhwc(lin.weight.contiguous(), buf, fo, _rup(fo, 128), p_)
+                else:
+                    ops.cast_pad(lin.weight.contiguous(), buf, fo, fi, _rup(fo, 128), fi)
+                fcw.append(buf)
+            pk['fc_w'] = fcw
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, program):
+        N = x.size(0)
+        assert N == len(program)
+        if type(program) is list or type(program) is tuple:
+            # the reference's list-of-dicts path reads self.function_modules, which its __init__
+            # never sets (Module_Model.py:136,149,186): it raises AttributeError, and so do we
+            raise AttributeError("'ModuleNet' object has no attribute 'function_modules'")
+        elif type(program) is torch.Tensor and program.dim() == 2:
+            pass
+        else:
+            raise ValueError('Unregonized program format')
+        if not x.is_cuda:
+            raise RuntimeError('vqa_amd.ModuleNet runs on an MI355X only: features must be a CUDA/HIP '
+                               'tensor (no CPU fallback)')
+        _lib.load()
+        plan = Plan(program.detach().cpu().numpy(), self.vocab, self._dims['c'], self.wgrad_chunk)
+        # Module_Model.py:227,231: a float tensor on the program's device
+        self.used_fns = torch.from_numpy(plan.used_fns()).to(program.device)
+        params = [p for _, p in self._param_groups()]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _ExecFn.apply(self, x, plan, need_grad, *params)
+
+    def _conv(self, st, src, dst, w, tiles_sec, taps, k_chunks, n_out, src_geo, dst_geo, **kw):
+        off, cnt = st['plan'].section(tiles_sec)
+        ops.conv_tiles(src, dst, w, st['blob'], cnt, taps=taps, k_chunks=k_chunks, n_out=n_out,
+                       src_slot_stride=src_geo[0], src_pix_stride=src_geo[1],
+                       dst_slot_stride=dst_geo[0], dst_pix_stride=dst_geo[1],
+                       w_group_stride=0, tiles_offset=off, **kw)
+
+    def _tree_ctx(self, st, pk, grads=None):
+        ctx = _lib.TreeCtx()
+        ctx.arena, ctx.blob = st['arena'].data_ptr(), st['blob'].data_ptr()
+        for k in ('w_conv1', 'w_conv2', 'w_proj', 'wd_conv1', 'wd_conv2', 'wd_proj',
+                  'b_conv1', 'b_conv2', 'b_proj'):
+            setattr(ctx, k, pk[k].data_ptr())
+        if grads is not None:
+            for k in ('g_conv1', 'g_conv2', 'g_proj', 'gb_conv1', 'gb_conv2', 'gb_proj'):
+                setattr(ctx, k, grads[k].data_ptr())
+        ctx.C, ctx.V = self._dims['c'], len(self._tokens)
+        return ctx
+
+    def _run_forward(self, x, plan, need_grad):
+        d = self._dims
+        dev = x.device
+        N, c, p_, cpad = plan.N, d['c'], d['p'], d['cin_pad']
+        if x.dim() != 4 or tuple(x.shape[1:]) != (d['cin'], 14, 14):
+            raise ValueError('features must be [N, %d, 14, 14]' % d['cin'])
+        pk = self._pack_weights(dev)
+        ws, info = self._ws, plan.info
+        st = {'plan': plan, 'N': N, 'pk': pk}
+        blob_host = torch.from_numpy(plan.blob())
+        st['blob'] = ws.get('blob', blob_host.numel(), torch.int32, dev)
+        st['blob'].copy_(blob_host)
+        slots = info.slots_total if need_grad else info.slots_fwd
+        st['arena'] = arena = ws.get('arena', slots * HW * c, torch.bfloat16, dev)
+        xs = x.detach().to(torch.float32).contiguous()
+        st['x_nhwc'] = xn = ws.get('x_nhwc', N * HW * cpad, torch.bfloat16, dev)
+        ops.nchw_to_nhwc(xs, xn, N, d['cin'], cpad)
+        slot = (HW * c, c)
+        # stem: two conv3x3 + bias + ReLU over the whole batch (Module_Model.py:55-64,239)
+        self._conv(st, xn, arena, pk['w_stem0'], 'STEM0_TILES', 9, cpad // 128, c, (HW * cpad, cpad), slot,
+                   bias=pk['b_stem0'], relu=True)
+        self._conv(st, arena, arena, pk['w_stem1'], 'STEM1_TILES', 9, c // 128, c, slot, slot,
+                   bias=pk['b_stem1'], relu=True)
+        # module trees, level by level
+        tctx = self._tree_ctx(st, pk)
+        _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
+        # classifier (Module_Model.py:66-93, default: no pooling): conv1x1 + ReLU on the gathered
+        # roots, flatten, linear layers
+        np128 = _rup(N, 128)
+        st['c1'] = c1 = ws.get('c1', np128 * HW * p_, torch.bfloat16, dev)
+        if np128 != N:
+            c1.view(np128, HW * p_)[N:].zero_()   # padding rows feed GEMM tiles: keep them finite
+        self._conv(st, arena, c1, pk['w_cls'], 'CLS_FWD_TILES', 1, c // 128, p_, slot, (HW * p_, p_),
+                   bias=pk['b_cls'], relu=True)
+        acts = [c1]
+        prev_dim = HW * p_
+        fcs = list(d['fcs']) + [d['na']]
+        for li, fo in enumerate(fcs):
+            lin = self.classifier[self._fc_idx[li]]
+            last = li == len(fcs) - 1
+            tiles = (np128 // 128) * (_rup(fo, 128) // 128)
+            split = max(1, min(prev_dim // 64, 16, -(-512 // tiles)))
+            acc = ws.get('fc_acc%d' % li, split * N * fo, torch.float32, dev)
+            ops.gemm(acts[-1], pk['fc_w'][li], acc, N, fo, prev_dim, lda=prev_dim, ldb=prev_dim, ldc=fo,
+                     split_k=split)
+            if last:
+                logits = torch.empty(N, fo, dtype=torch.float32, device=dev)
+                ops.bias_act(acc, lin.bias.detach(), logits, N, fo, fo, fo, False, slabs=split, slab_stride=N * fo)
+                st['logits'] = logits
+            else:
+                a = ws.get('fc_act%d' % li, np128 * fo, torch.bfloat16, dev)
+                if np128 != N:
+                    a.view(np128, fo)[N:].zero_()
+                ops.bias_act(acc, lin.bias.detach(), a, N, fo, fo, fo, True, slabs=split, slab_stride=N * fo)
+                acts.append(a)
+                prev_dim = fo
+        st['acts'] = acts
+        if self.keep_state:
+            self.last_state = st
+        return st
+
+    def stored_activation(self, st, kind, index=0):
+        """A stored forward activation of call `st` as an fp32 CPU tensor in the reference's NCHW
+        layout: kinds 'S0', 'F', 'C1', ('FC', layer) are whole-batch, 'H', 'Y' take a node id and
+        'P' a binary-node index (execution order).  For tests and debugging."""
+        d, plan, N = self._dims, st['plan'], st['N']
+        c = d['c']
+        arena = st['arena'].view(-1, HW, c)
+
+        def nchw(t, ch):
+            return t.to(torch.float32).cpu().reshape(-1, HW, ch).permute(0, 2, 1).reshape(-1, ch, 14, 14)
+        if kind in ('S0', 'F'):
+            s0 = plan.slot(kind, 0)
+            return nchw(arena[s0:s0 + N], c)
+        if kind in ('H', 'Y'):
+            return nchw(arena[plan.slot(kind, index)], c)
+        if kind == 'P':
+            base = plan.slot('H', 0) + plan.info.num_nodes
+            return nchw(arena[base + index], c)
+        if kind == 'C1':
+            return nchw(st['c1'].view(-1, HW, d['p'])[:N], d['p'])
+        if isinstance(kind, tuple) and kind[0] == 'FC':
+            a = st['acts'][kind[1] + 1]
+            return a.view(-1, d['fcs'][kind[1]])[:N].to(torch.float32).cpu()
+        raise KeyError(kind)
+
+    # ------------------------------------------------------------------ backward
+    def _run_backward(self, st, dlogits):
+        d = self._dims
+        plan, pk, N = st['plan'], st['pk'], st['N']
+        dev = dlogits.device
+        ws, lib = self._ws, _lib.load()
+        c, p_, cpad, nv = d['c'], d['p'], d['cin_pad'], len(self._tokens)
+        np128, np64 = _rup(N, 128), _rup(N, 64)
+        arena, blob, acts = st['arena'], st['blob'], st['acts']
+        slot = (HW * c, c)
+        fcs = list(d['fcs']) + [d['na']]
+        dims_in = [HW * p_] + list(d['fcs'])
+        f32 = dict(dtype=torch.float32, device=dev)
+        grads = {}
+
+        # ---- linear layers, last to first
+        g = ws.get('dlog', np128 * d['na_pad'], torch.bfloat16, dev)
+        dl = dlogits.detach().to(torch.float32).contiguous()
+        ops.cast_pad(dl, g, N, d['na'], np128, d['na_pad'])
+        gb = torch.zeros(d['na'], **f32)
+        ops.col_sum(dl, gb, N, d['na'], d['na'])
+        grads['classifier.%d.bias' % self._fc_idx[-1]] = gb
+        g_ld = d['na_pad']
+        for li in range(len(fcs) - 1, -1, -1):
+            fo, fi = fcs[li], dims_in[li]
+            name = 'classifier.%d' % self._fc_idx[li]
+            # weight gradient: dW[fo][fi] = g^T (rows = samples) x input activations
+            gw = torch.empty(fo, fi, **f32)
+            tmp = gw if li > 0 else ws.get('fc0_gw', fo * fi, torch.float32, dev)
+            ops.gemm(g, acts[li], tmp, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
+            if li == 0:
+                ops.fc_grad_from_nhwc(tmp, gw, fo, p_)
+            grads[name + '.weight'] = gw
+            # input gradient, masked by the ReLU that produced the input
+            gin = ws.get('fc_gin%d' % li, np128 * fi, torch.bfloat16, dev)
+            if np128 != N:
+                gin.view(np128, fi)[N:].zero_()   # rows past N are the K padding of the next GEMM
+            kdim = g_ld if li == len(fcs) - 1 else fo
+            ops.gemm(g, pk['fc_w'][li], gin, N, fi, kdim, lda=g_ld, ldb=fi, ldc=fi, b_kmajor=True,
+                     out_bf16=True, mask=acts[li])
+            g, g_ld = gin, fi
+            if li > 0:
+                gb = torch.zeros(fi, **f32)
+                ops.col_sum(gin, gb, N, fi, fi)
+                grads['classifier.%d.bias' % self._fc_idx[li - 1]] = gb
+        dc1 = g   # bf16 [N][196][P], already times (C1 > 0)
+
+        # ---- classifier conv1x1: weight/bias gradient, then gradient into the roots' dZ slots
+        it_off, it_cnt = plan.section('SAMPLE_ITEMS')
+        sec = lambda n: (blob, plan.section(n)[0])
+        gcw = torch.zeros(1, 1, c, p_, **f32)
+        gcb = torch.zeros(p_, **f32)
+        ops.wgrad_tiles(arena, dc1, (blob, it_off), it_cnt, sec('SLOTS_ROOTY'), sec('SLOTS_IDENT'), gcw, gcb,
+                        taps=1, k_chunks=c // 128, n_out=p_, src_slot_stride=HW * c, dy_slot_stride=HW * p_,
+                        src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_)
+        gw = torch.empty(p_, c, 1, 1, **f32)
+        ops.unpack_conv_grad(gcw, gw, 1, p_, c, 1, 0)
+        grads['classifier.0.weight'], grads['classifier.0.bias'] = gw, gcb
+        self._conv(st, dc1, arena, pk['wd_cls'], 'CLS_DGRAD_TILES', 1, p_ // 128, c, (HW * p_, p_), slot,
+                   mask=arena)
+
+        # ---- module trees: input gradients by level, scene fan-in, all weight gradients
+        acc = {'g_conv1': torch.zeros(nv, 9, c, c, **f32), 'g_conv2': torch.zeros(nv, 9, c, c, **f32),
+               'g_proj': torch.zeros(nv, 2 * c, c, **f32), 'gb_conv1': torch.zeros(nv, c, **f32),
+               'gb_conv2': torch.zeros(nv, c, **f32), 'gb_proj': torch.zeros(nv, c, **f32)}
+        tctx = self._tree_ctx(st, pk, acc)
+        _lib.check(lib.vqa_tree_backward(plan.handle, C.byref(tctx), ops._stream()))
+        gw1 = torch.empty(nv, c, c, 3, 3, **f32)
+        gw2 = torch.empty(nv, c, c, 3, 3, **f32)
+        gwp = torch.empty(nv, c, 2 * c, 1, 1, **f32)
+        ops.unpack_conv_grad(acc['g_conv1'], gw1, nv, c, c, 9, c * c * 9)
+        ops.unpack_conv_grad(acc['g_conv2'], gw2, nv, c, c, 9, c * c * 9)
+        ops.unpack_conv_grad(acc['g_proj'], gwp, nv, c, 2 * c, 1, 2 * c * c)
+        counts = plan.token_counts()
+        for i, tok in enumerate(self._tokens):
+            if counts[i] == 0:
+                continue      # unused in this batch: .grad stays None, as with the reference
+            if self._binary[i]:
+                grads[tok + '.proj.weight'], grads[tok + '.proj.bias'] = gwp[i], acc['gb_proj'][i]
+            grads[tok + '.conv1.weight'], grads[tok + '.conv1.bias'] = gw1[i], acc['gb_conv1'][i]
+            grads[tok + '.conv2.weight'], grads[tok + '.conv2.bias'] = gw2[i], acc['gb_conv2'][i]
+
+        # ---- stem: dS0 = dgrad(dF) * (S0 > 0); weight gradients of both convs (no d/dx)
+        self._conv(st, arena, arena, pk['wd_stem1'], 'STEM1_DGRAD_TILES', 9, c // 128, c, slot, slot, mask=arena)
+        gs1, gs1b = torch.zeros(1, 9, c, c, **f32), torch.zeros(c, **f32)
+        ops.wgrad_tiles(arena, arena, (blob, it_off), it_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), gs1, gs1b,
+                        taps=9, k_chunks=c // 128, n_out=c, src_slot_stride=HW * c, dy_slot_stride=HW * c,
+                        src_pix_stride=c, dy_pix_stride=c, dw_group_stride=9 * c * c)
+        gs0, gs0b = torch.zeros(1, 9, cpad, c, **f32), torch.zeros(c, **f32)
+        ops.wgrad_tiles(st['x_nhwc'], arena, (blob, it_off), it_cnt, sec('SLOTS_IDENT'), sec('SLOTS_DS0'), gs0, gs0b,
+                        taps=9, k_chunks=cpad // 128, n_out=c, src_slot_stride=HW * cpad, dy_slot_stride=HW * c,
+                        src_pix_stride=cpad, dy_pix_stride=c, dw_group_stride=9 * cpad * c)
+        gw = torch.empty(c, c, 3, 3, **f32)
+        ops.unpack_conv_grad(gs1, gw, 1, c, c, 9, 0)
+        grads['stem.2.weight'], grads['stem.2.bias'] = gw, gs1b
+        gw = torch.empty(c, cpad, 3, 3, **f32)
+        ops.unpack_conv_grad(gs0, gw, 1, c, cpad, 9, 0)
+        grads['stem.0.weight'] = gw[:, :d['cin']].contiguous() if cpad != d['cin'] else gw
+        grads['stem.0.bias'] = gs0b
+
+        out = []
+        for name, p in self._param_groups():
+            gr = grads.get(name)
+            if gr is not None:
+                gr = gr.reshape(p.shape)
+                if self.grad_ready_hook is not None:
+                    self.grad_ready_hook(name, gr)
+            out.append(gr if p.requires_grad else None)
+        return out
