@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the module-executor train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over one synthetic CLEVR-shape batch per GPU: features
+NCHW fp32 -> executor forward -> cross-entropy -> executor backward -> gradient all-reduce (N > 1)
+-> Adam step (Train_model.py:306-315).  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vqa_amd import ops, synth, vocab as V  # noqa: E402
+from vqa_amd.schedule import Plan  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=1024, help='programs per GPU')
+    ap.add_argument('--module-dim', type=int, default=128)
+    ap.add_argument('--max-len', type=int, default=30)
+    ap.add_argument('--max-nodes', type=int, default=27)
+    ap.add_argument('--batches', type=int, default=4, help='distinct resident synthetic batches cycled through')
+    ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=768, help='programs in the CPU baseline sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(vocab, sample):
+    """The CPU restatement of the reference executor (oracle/, per-sample reference order, stock
+    torch fp32 ops) on a bounded sample of the same synthetic workload: forward + loss + backward."""
+    from oracle.module_net_ref import ModuleNetRef
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = synth.synth_state_dict(17, vocab)
+    ref = ModuleNetRef(vocab, sd)
+    prog = torch.from_numpy(synth.synth_programs(1001, sample, vocab))
+    x = torch.from_numpy(synth.synth_features(1001, sample))
+    ans = torch.from_numpy(synth.synth_answers(1001, sample))
+    ref(x[:2], prog[:2]).sum().backward()        # warm-up
+    t0 = time.perf_counter()
+    torch.nn.functional.cross_entropy(ref(x, prog), ans).backward()
+    dt = time.perf_counter() - t0
+    return {'value': sample / dt, 'unit': 'programs/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d programs of the same synthetic workload, fp32, forward + cross-entropy + '
+                      'backward once (%.1f s)' % (sample, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run '
+                             '--nproc-per-node %d' % (a.gpus, a.gpus))
+        a.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from vqa_amd.module_net import ModuleNet
+    vocab = V.make_vocab()
+    net = ModuleNet(False, vocab, module_dim=a.module_dim)
+    net.load_state_dict(synth.synth_state_dict(17, vocab, module_dim=a.module_dim))   # identical replicas
+    net.to(dev).train()
+    step_net = net
+    if world > 1:
+        from vqa_amd.dp import DataParallelExecutor
+        step_net = DataParallelExecutor(net)
+    opt = None
+    if not a.no_optimizer:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=5e-5, fused=True)   # Train_model.py:165-167
+    loss_fn = torch.nn.CrossEntropyLoss()
+
+    # resident synthetic batches (seed = 1000*config + rank, config 3)
+    batches, flops_step, nodes_step = [], [], []
+    for b in range(a.batches):
+        seed = 3000 + rank + 100 * b
+        prog = synth.synth_programs(seed, a.batch, vocab, max_len=a.max_len, max_nodes=a.max_nodes)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        x = torch.randn(a.batch, 1024, 14, 14, device=dev, generator=g).clamp_(min=0)
+        ans = torch.from_numpy(synth.synth_answers(seed, a.batch)).to(dev)
+        plan = Plan(prog, vocab, a.module_dim)
+        flops_step.append(plan.flops()[1])
+        nodes_step.append(plan.info.num_nodes)
+        batches.append((x, torch.from_numpy(prog).to(dev), ans))
+
+    def step(i):
+        x, prog, ans = batches[i % len(batches)]
+        if opt is not None:
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in net.parameters():
+                p.grad = None
+        loss = loss_fn(step_net(x, prog), ans)
+        loss.backward()
+        if world > 1:
+            step_net.finish_grad_sync()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    ops.prof_enable(True)
+    ops.prof_collect()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(False)
+    prof = ops.prof_collect()
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        idx = [(a.warmup + i) % len(batches) for i in range(a.steps)]
+        flops = sum(flops_step[j] for j in idx) / a.steps            # per rank per step (rank 0's batches)
+        k = prof['conv3x3']
+        ach = k['flops'] / (k['ms'] * 1e-3) / 1e12 if k['ms'] > 0 else 0.0
+        out = {
+            'metric': 'programs/sec (module-net fwd+bwd, whole node)',
+            'value': a.batch * world * a.steps / dt,
+            'unit': 'programs/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': dt / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'executor train step (fwd + cross-entropy + bwd%s%s), bf16 MFMA with fp32 '
+                                   'accumulation, batch %d/GPU, default 117.5 M-parameter ModuleNet, random '
+                                   'well-formed CLEVR-style programs (<=%d nodes, T=%d, mean %.1f nodes), '
+                                   'features [N,1024,14,14] fp32 resident in HBM'
+                                   % (' + RCCL gradient all-reduce' if world > 1 else '',
+                                      '' if a.no_optimizer else ' + fused Adam', a.batch, a.max_nodes, a.max_len,
+                                      float(np.mean(nodes_step)) / a.batch),
+                       'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
+            'model_tflops': flops * world * a.steps / dt / 1e12,
+            'mfma_peak_frac': flops * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_tiles_kernel<9> (grouped 3x3 implicit-GEMM conv: forward '
+                                                    'and input-gradient launches)',
+                         'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
+                         'launches': k['launches'], 'avg_launch_ms': k['ms'] / max(k['launches'], 1)},
+            'kernels': {n: {'launches': v['launches'], 'ms_per_step': v['ms'] / a.steps,
+                            'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
+                        for n, v in prof.items()},
+            'loss': float(loss.detach()),
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(vocab, a.cpu_sample)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -177,6 +177,8 @@ typedef struct {
     int32_t pair_chunks;        /* as in vqa_conv_params */
     int32_t n_out;              /* channels of dy (o), multiple of 64 */
     int32_t num_items;
+    int32_t total_nodes;        /* sum of the items' counts (work accounting only) */
+    int32_t reserved;
 } vqa_wgrad_params;
 
 int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* stream);
@@ -232,6 +234,15 @@ int vqa_col_sum(const void* x, float* out, int32_t rows, int32_t cols, int64_t l
 int vqa_slot_sum_mask(void* arena, const int32_t* offsets, const int32_t* src_slots,
                       const int32_t* dst_slots, const int32_t* mask_slots, int32_t n_dst,
                       int64_t slot_elems, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing for the benchmark (no counterpart in the reference).  While enabled, every
+ * launch of the MFMA kernels is bracketed by HIP events on its stream.  vqa_prof_collect waits for
+ * them and writes, per kind k (0 conv3x3, 1 conv1x1, 2 wgrad3x3, 3 wgrad1x1, 4 gemm):
+ * out[4k] launches, out[4k+1] total ms, out[4k+2] algorithmic FLOPs, out[4k+3] algorithmic bytes.
+ * ------------------------------------------------------------------------------------------ */
+int vqa_prof_enable(int32_t on);
+int vqa_prof_collect(double* out, int32_t kinds);
 
 /* ------------------------------------------------------------------------------------------
  * Whole module tree.  Replaces forward_modules_ints (Module_Model.py:224-233) and autograd's

@@ -33,7 +33,7 @@ class WgradParams(C.Structure):
                 ('dy_slots', vp), ('dw', vp), ('db', vp), ('src_slot_stride', i64),
                 ('dy_slot_stride', i64), ('dw_group_stride', i64), ('src_pix_stride', i32),
                 ('dy_pix_stride', i32), ('k_chunks', i32), ('pair_chunks', i32), ('n_out', i32),
-                ('num_items', i32)]
+                ('num_items', i32), ('total_nodes', i32), ('reserved', i32)]
 
 
 class GemmParams(C.Structure):
@@ -89,6 +89,8 @@ SIGNATURES = {
     'vqa_bias_act': (i32, [vp, vp, vp, i32, i32, i64, i64, i32, i32, i64, i32, vp]),
     'vqa_col_sum': (i32, [vp, vp, i32, i32, i64, i32, vp]),
     'vqa_slot_sum_mask': (i32, [vp, vp, vp, vp, vp, i32, i64, vp]),
+    'vqa_prof_enable': (i32, [i32]),
+    'vqa_prof_collect': (i32, [C.POINTER(C.c_double), i32]),
     'vqa_tree_forward': (i32, [vp, C.POINTER(TreeCtx), vp]),
     'vqa_tree_backward': (i32, [vp, C.POINTER(TreeCtx), vp]),
 }
@@ -105,6 +107,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it carries its own HIP runtime, and the library must bind to that one (two
+    # runtimes in one process do not share devices or streams)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError('%s is missing: build it with `python -m vqa_amd.build` '
                           '(there is no CPU fallback)' % LIB_PATH)

@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libvqa_amd.so')
-SOURCES = ['schedule.cpp', 'tree.cpp', 'conv.hip', 'wgrad.hip', 'gemm.hip', 'misc.hip']
-HEADERS = ['vqa_dev.h', 'plan.h', os.path.join('..', '..', 'include', 'vqa_amd.h')]
+SOURCES = ['schedule.cpp', 'tree.cpp', 'prof.cpp', 'conv.hip', 'wgrad.hip', 'gemm.hip', 'misc.hip']
+HEADERS = ['vqa_dev.h', 'plan.h', 'prof.h', os.path.join('..', '..', 'include', 'vqa_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-unused-function']
 
@@ -24,6 +24,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(OUT, [os.path.join(CSRC, s) for s in SOURCES] + hdrs):
+        return OUT          # up to date (object files need not exist: they do not travel)
     objs = []
     procs = []
     for s in SOURCES:

@@ -12,6 +12,7 @@
 // its stem (Module_Model.py:59-62) and classifier 1x1 conv (:72-75).
 #include "vqa_dev.h"
 #include "plan.h"
+#include "prof.h"
 
 #define HALO_STRIDE 288
 #define HALO_POS 264
@@ -171,6 +172,9 @@ extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stre
         attr_set = true;
     }
     dim3 grid(p->num_tiles, p->n_out / 128), block(256);
+    const double kdim = (double)p->k_chunks * 128 * taps;
+    VqaProfScope prof(taps == 9 ? VQA_K_CONV9 : VQA_K_CONV1, 2.0 * VQA_HW * kdim * p->n_out * p->num_tiles,
+                      (double)p->num_tiles * VQA_HW * 2.0 * (p->k_chunks * 128 + p->n_out), (hipStream_t)stream);
     if (taps == 9) hipLaunchKernelGGL(conv_tiles_kernel<9>, grid, block, CONV_LDS, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(conv_tiles_kernel<1>, grid, block, CONV_LDS, (hipStream_t)stream, *p);
     hipError_t e = hipGetLastError();

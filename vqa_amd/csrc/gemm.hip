@@ -10,6 +10,7 @@
 // Replaces nn.Linear of Module_Model.py:85,92 and autograd's gradients of it.
 #include "vqa_dev.h"
 #include "plan.h"
+#include "prof.h"
 
 #define GT_BYTES 16384   // one operand stage: 128 x 64 bf16
 
@@ -155,6 +156,8 @@ extern "C" int vqa_gemm(const vqa_gemm_params* p, void* stream) {
     }
     dim3 grid((p->N + 127) / 128, (p->M + 127) / 128, p->split_k), block(256);
     hipStream_t s = (hipStream_t)stream;
+    VqaProfScope prof(VQA_K_GEMM, 2.0 * p->M * (double)p->N * p->K,
+                      2.0 * ((double)p->M * p->K + (double)p->N * p->K) + (p->out_mode == 2 ? 2.0 : 4.0) * p->M * (double)p->N, s);
     if (!p->a_kmajor && !p->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, s, *p);
     else if (!p->a_kmajor && p->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, s, *p);
     else if (p->a_kmajor && p->b_kmajor) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, s, *p);

@@ -1,0 +1,65 @@
+// Per-kernel timing: a pair of HIP events around every launch of the MFMA kernels while
+// profiling is enabled, resolved at vqa_prof_collect.  Used by bench.py for the roofline figure.
+#include "prof.h"
+#include "plan.h"
+
+#include <mutex>
+#include <vector>
+
+namespace {
+struct Rec { int kind; double flops, bytes; hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+Rec g_open;
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool vqa_prof_on() { return g_on; }
+
+void vqa_prof_begin(int kind, double flops, double bytes, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_open = Rec{kind, flops, bytes, get_event(), get_event()};
+    (void)hipEventRecord(g_open.a, s);
+}
+
+void vqa_prof_end(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipEventRecord(g_open.b, s);
+    g_recs.push_back(g_open);
+}
+
+extern "C" int vqa_prof_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return VQA_OK;
+}
+
+// Waits for the recorded launches, then adds per kind: out[kind*4 + 0] launches, +1 total ms,
+// +2 algorithmic FLOPs, +3 algorithmic bytes.  Clears the records.
+extern "C" int vqa_prof_collect(double* out, int32_t kinds) {
+    if (!out || kinds < VQA_K_COUNT) { vqa_set_error("vqa_prof_collect: need room for 5 kinds"); return VQA_EINVAL; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < kinds * 4; i++) out[i] = 0.0;
+    for (Rec& r : g_recs) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            out[r.kind * 4 + 0] += 1.0;
+            out[r.kind * 4 + 1] += ms;
+            out[r.kind * 4 + 2] += r.flops;
+            out[r.kind * 4 + 3] += r.bytes;
+        }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return VQA_OK;
+}

@@ -107,6 +107,7 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     w.n_out = pl->C;
     w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_ITEMS]);
     w.num_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
+    w.total_nodes = (int)pl->nodes.size();
     w.k_chunks = cc;
     w.dw_group_stride = w33;
     w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C1];
@@ -120,6 +121,7 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     if (pl->sec_cnt[VQA_SEC_WG_PITEMS] > 0) {
         w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_PITEMS]);
         w.num_items = pl->sec_cnt[VQA_SEC_WG_PITEMS];
+        w.total_nodes = pl->num_binary;
         w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_PSRC0];
         w.src1_slots = c->blob + pl->sec_off[VQA_SEC_WG_PSRC1];
         w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_PDY];

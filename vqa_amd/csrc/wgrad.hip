@@ -14,6 +14,7 @@
 // token's module (Train_model.py:313 over Module_Model.py:221).
 #include "vqa_dev.h"
 #include "plan.h"
+#include "prof.h"
 
 #define XH_STRIDE 288
 #define XH_POS 264
@@ -167,6 +168,9 @@ extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* st
         attr_set = true;
     }
     dim3 grid(p->num_items, p->n_out / 64, p->k_chunks), block(512);
+    VqaProfScope prof(taps == 9 ? VQA_K_WGRAD9 : VQA_K_WGRAD1,
+                      2.0 * VQA_HW * taps * p->k_chunks * 128.0 * p->n_out * p->total_nodes,
+                      (double)p->total_nodes * VQA_HW * 2.0 * (p->k_chunks * 128 + p->n_out), (hipStream_t)stream);
     if (taps == 9) hipLaunchKernelGGL(wgrad_tiles_kernel<9>, grid, block, WGRAD_LDS, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(wgrad_tiles_kernel<1>, grid, block, WGRAD_LDS, (hipStream_t)stream, *p);
     hipError_t e = hipGetLastError();

@@ -405,7 +405,7 @@ class ModuleNet(nn.Module):
         gcb = torch.zeros(p_, **f32)
         ops.wgrad_tiles(arena, dc1, (blob, it_off), it_cnt, sec('SLOTS_ROOTY'), sec('SLOTS_IDENT'), gcw, gcb,
                         taps=1, k_chunks=c // 128, n_out=p_, src_slot_stride=HW * c, dy_slot_stride=HW * p_,
-                        src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_)
+                        src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_, total_nodes=N)
         gw = torch.empty(p_, c, 1, 1, **f32)
         ops.unpack_conv_grad(gcw, gw, 1, p_, c, 1, 0)
         grads['classifier.0.weight'], grads['classifier.0.bias'] = gw, gcb
@@ -438,11 +438,11 @@ class ModuleNet(nn.Module):
         gs1, gs1b = torch.zeros(1, 9, c, c, **f32), torch.zeros(c, **f32)
         ops.wgrad_tiles(arena, arena, (blob, it_off), it_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), gs1, gs1b,
                         taps=9, k_chunks=c // 128, n_out=c, src_slot_stride=HW * c, dy_slot_stride=HW * c,
-                        src_pix_stride=c, dy_pix_stride=c, dw_group_stride=9 * c * c)
+                        src_pix_stride=c, dy_pix_stride=c, dw_group_stride=9 * c * c, total_nodes=N)
         gs0, gs0b = torch.zeros(1, 9, cpad, c, **f32), torch.zeros(c, **f32)
         ops.wgrad_tiles(st['x_nhwc'], arena, (blob, it_off), it_cnt, sec('SLOTS_IDENT'), sec('SLOTS_DS0'), gs0, gs0b,
                         taps=9, k_chunks=cpad // 128, n_out=c, src_slot_stride=HW * cpad, dy_slot_stride=HW * c,
-                        src_pix_stride=cpad, dy_pix_stride=c, dw_group_stride=9 * cpad * c)
+                        src_pix_stride=cpad, dy_pix_stride=c, dw_group_stride=9 * cpad * c, total_nodes=N)
         gw = torch.empty(c, c, 3, 3, **f32)
         ops.unpack_conv_grad(gs1, gw, 1, c, c, 9, 0)
         grads['stem.2.weight'], grads['stem.2.bias'] = gw, gs1b

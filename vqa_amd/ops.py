@@ -61,7 +61,7 @@ def pack_conv_weight(w, groups, n_out, k_in, taps, g_stride, n_stride, k_stride,
 
 def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps, k_chunks, n_out,
                 src_slot_stride, dy_slot_stride, src_pix_stride, dy_pix_stride, dw_group_stride,
-                src1_slots=None, pair_chunks=0):
+                src1_slots=None, pair_chunks=0, total_nodes=0):
     """items / *_slots are (tensor, word_offset) pairs into an int32 device blob."""
     p = _lib.WgradParams()
     p.src, p.dy = src.data_ptr(), dy.data_ptr()
@@ -74,6 +74,7 @@ def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps,
     p.src_slot_stride, p.dy_slot_stride, p.dw_group_stride = src_slot_stride, dy_slot_stride, dw_group_stride
     p.src_pix_stride, p.dy_pix_stride = src_pix_stride, dy_pix_stride
     p.k_chunks, p.pair_chunks, p.n_out, p.num_items = k_chunks, pair_chunks, n_out, num_items
+    p.total_nodes = total_nodes
     _lib.check(_lib.load().vqa_wgrad_tiles(C.byref(p), taps, _stream()))
 
 
@@ -131,3 +132,18 @@ def slot_sum_mask(arena, blob, off_offsets, off_src, off_dst, off_mask, n_dst, s
     _lib.check(_lib.load().vqa_slot_sum_mask(_ptr(arena), C.c_void_p(b + 4 * off_offsets),
                                              C.c_void_p(b + 4 * off_src), C.c_void_p(b + 4 * off_dst),
                                              C.c_void_p(b + 4 * off_mask), n_dst, slot_elems, _stream()))
+
+
+KERNEL_KINDS = ('conv3x3', 'conv1x1', 'wgrad3x3', 'wgrad1x1', 'gemm')
+
+
+def prof_enable(on):
+    _lib.check(_lib.load().vqa_prof_enable(int(on)))
+
+
+def prof_collect():
+    """{kind: dict(launches, ms, flops, bytes)} of the launches since the last collect."""
+    out = (C.c_double * (4 * len(KERNEL_KINDS)))()
+    _lib.check(_lib.load().vqa_prof_collect(out, len(KERNEL_KINDS)))
+    return {k: dict(launches=int(out[4 * i]), ms=out[4 * i + 1], flops=out[4 * i + 2], bytes=out[4 * i + 3])
+            for i, k in enumerate(KERNEL_KINDS)}
