@@ -1,0 +1,151 @@
+"""Data-parallel training of the executor: one process per GPU, RCCL gradient all-reduce.
+
+Replaces `torch.nn.DataParallel(ee)` (`Functions.py:122-126`), which re-broadcasts all 117 M
+parameters to every replica on every forward and reduces gradients to device 0.  Here every rank
+keeps a persistent replica, owns rows [r*N/G, (r+1)*N/G) of the batch (the same split
+DataParallel's scatter makes), and the only collective on the data path is the gradient
+all-reduce:
+
+  * the first linear layer's gradient (411 MB of the 470 MB) is produced first in backward; its
+    all-reduce is launched the moment its kernel is enqueued and runs on RCCL's stream under the
+    whole module-tree backward
+  * every other gradient goes into one flat fp32 bucket with a fixed layout, reduced when backward
+    ends; a token that no program of this rank used contributes zeros, so every rank issues
+    identical collectives whatever its programs were
+  * a parameter keeps `grad is None` only if NO rank used its token, which is what the
+    reference's reduce-add over replicas gives (Adam then skips it, weight decay included)
+
+The wrapper works on any backend torch.distributed offers (tests run it on gloo/CPU with a
+stand-in module); on MI355X the backend is "nccl", i.e. RCCL over xGMI.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n, rank, world):
+    """Row range of rank `rank` when `n` samples are split over `world` ranks as
+    torch.nn.DataParallel's scatter does (ceil-sized chunks)."""
+    per = -(-n // world)
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+class DataParallelExecutor:
+    def __init__(self, net, process_group=None, direct_bytes=32 << 20):
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self.net = net
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.direct_bytes = direct_bytes
+        self._params = list(net._param_groups())
+        self._names = [n for n, _ in self._params]
+        self._token_of = {}
+        toks = getattr(net, '_tokens', [])
+        for ti, tok in enumerate(toks):
+            for n in self._names:
+                if n.startswith(tok + '.'):
+                    self._token_of[n] = ti
+        self._flat = None
+        self._layout = None
+        self._works = []
+        self._direct = {}
+        self._small = {}
+        self._presence = None
+        self._pending = False
+        net.grad_ready_hook = self._on_grad
+        net.backward_done_hook = self._on_backward_done
+        self._avg = dist.get_backend(process_group) == 'nccl'
+
+    # ---------------------------------------------------------------- forward
+    def __call__(self, x, program):
+        return self.forward(x, program)
+
+    def forward(self, x, program):
+        out = self.net(x, program)
+        counts = getattr(self.net, 'last_token_counts', None)
+        if counts is not None and torch.is_grad_enabled():
+            self._presence = torch.as_tensor(counts, dtype=torch.int32).clamp(max=1).to(out.device)
+            self._works.append(dist.all_reduce(self._presence, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
+        return out
+
+    # ---------------------------------------------------------------- backward hooks
+    def _reduce(self, t):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._works.append(dist.all_reduce(t, op=op, group=self.pg, async_op=True))
+
+    def _on_grad(self, name, grad):
+        self._pending = True
+        if grad.numel() * grad.element_size() >= self.direct_bytes and grad.is_contiguous():
+            self._direct[name] = grad
+            self._reduce(grad)               # in place, overlapped with the rest of backward
+        else:
+            self._small[name] = grad
+
+    def _ensure_flat(self, device):
+        if self._flat is not None and self._flat.device == device:
+            return
+        layout, off = {}, 0
+        for n, p in self._params:
+            if p.numel() * 4 >= self.direct_bytes:
+                continue
+            layout[n] = (off, p.numel())
+            off += p.numel()
+        self._layout = layout
+        self._flat = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def _on_backward_done(self):
+        dev = next(iter(self._small.values())).device if self._small else self._params[0][1].device
+        self._ensure_flat(dev)
+        self._flat.zero_()
+        for n, g in self._small.items():
+            off, cnt = self._layout[n]
+            self._flat[off:off + cnt].copy_(g.reshape(-1))
+        self._reduce(self._flat)
+
+    # ---------------------------------------------------------------- after loss.backward()
+    def finish_grad_sync(self):
+        """Wait for the collectives and install the averaged gradients on the parameters."""
+        if not self._pending:
+            return
+        for w in self._works:
+            w.wait()
+        self._works = []
+        present = None
+        if self._presence is not None:
+            present = self._presence.cpu().tolist()
+        scale = 1.0 if self._avg else 1.0 / self.world
+        if not self._avg:
+            self._flat.mul_(scale)
+        for n, p in self._params:
+            if n in self._direct:
+                g = self._direct[n]
+                if not self._avg:
+                    g.mul_(scale)
+                p.grad = g.reshape(p.shape)
+                continue
+            if n not in self._layout:
+                continue
+            ti = self._token_of.get(n)
+            if ti is not None and present is not None and not present[ti]:
+                p.grad = None                 # unused on every rank
+                continue
+            off, cnt = self._layout[n]
+            p.grad = self._flat[off:off + cnt].view(p.shape)
+        self._direct, self._small, self._presence, self._pending = {}, {}, None, False
+
+    # convenience passthroughs
+    def parameters(self):
+        return self.net.parameters()
+
+    def state_dict(self):
+        return self.net.state_dict()
+
+    def train(self, mode=True):
+        self.net.train(mode)
+        return self
+
+    def eval(self):
+        self.net.eval()
+        return self

@@ -149,7 +149,9 @@ class ModuleNet(nn.Module):
         self._packed = {}
         self.used_fns = None
         self.wgrad_chunk = 16
-        self.grad_ready_hook = None   # set by the data-parallel wrapper
+        self.grad_ready_hook = None   # set by the data-parallel wrapper: called as (name, grad tensor)
+        self.backward_done_hook = None
+        self.last_token_counts = None
         self.keep_state = False       # tests: keep the last call's buffers in self.last_state
         self.last_state = None
 
@@ -242,6 +244,7 @@ class ModuleNet(nn.Module):
         plan = Plan(program.detach().cpu().numpy(), self.vocab, self._dims['c'], self.wgrad_chunk)
         # Module_Model.py:227,231: a float tensor on the program's device
         self.used_fns = torch.from_numpy(plan.used_fns()).to(program.device)
+        self.last_token_counts = plan.token_counts()
         params = [p for _, p in self._param_groups()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _ExecFn.apply(self, x, plan, need_grad, *params)
@@ -365,6 +368,7 @@ class ModuleNet(nn.Module):
         dims_in = [HW * p_] + list(d['fcs'])
         f32 = dict(dtype=torch.float32, device=dev)
         grads = {}
+        emitted = set()
 
         # ---- linear layers, last to first
         g = ws.get('dlog', np128 * d['na_pad'], torch.bfloat16, dev)
@@ -384,6 +388,9 @@ class ModuleNet(nn.Module):
             if li == 0:
                 ops.fc_grad_from_nhwc(tmp, gw, fo, p_)
             grads[name + '.weight'] = gw
+            if self.grad_ready_hook is not None:     # the big one first: its all-reduce overlaps the rest
+                self.grad_ready_hook(name + '.weight', gw)
+                emitted.add(name + '.weight')
             # input gradient, masked by the ReLU that produced the input
             gin = ws.get('fc_gin%d' % li, np128 * fi, torch.bfloat16, dev)
             if np128 != N:
@@ -456,7 +463,9 @@ class ModuleNet(nn.Module):
             gr = grads.get(name)
             if gr is not None:
                 gr = gr.reshape(p.shape)
-                if self.grad_ready_hook is not None:
+                if self.grad_ready_hook is not None and name not in emitted:
                     self.grad_ready_hook(name, gr)
             out.append(gr if p.requires_grad else None)
+        if self.backward_done_hook is not None:
+            self.backward_done_hook()
         return out
