@@ -47,21 +47,70 @@ class _Flatten(nn.Module):
 
 
 class _Workspace:
-    """The caller-owned device buffers of the C ABI.  Every call gets fresh tensors from torch's
-    caching allocator, so a forward whose backward is still pending is never overwritten by
-    another forward (MAPO scoring runs eval forwards between a train forward and its backward,
-    Train_model.py:339-369)."""
+    """One set of the caller-owned device buffers of the C ABI: grow-only, reused call after call,
+    so a steady training loop allocates nothing here."""
+
+    def __init__(self):
+        self.bufs = {}
+        self.busy = False
 
     def get(self, name, numel, dtype, device, zero=False):
-        return (torch.zeros if zero else torch.empty)(numel, dtype=dtype, device=device)
+        t = self.bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype or t.device != device:
+            t = torch.empty(numel + numel // 8, dtype=dtype, device=device)   # headroom: sizes vary per batch
+            self.bufs[name] = t
+        t = t[:numel]
+        if zero:
+            t.zero_()
+        return t
+
+
+class _WorkspacePool:
+    """A forward whose backward is still pending keeps its workspace; any other forward in between
+    (MAPO scoring runs eval forwards between a train forward and its backward,
+    Train_model.py:339-369) takes another set.  Steady state: one set."""
+
+    def __init__(self):
+        self.sets = []
+
+    def acquire(self):
+        for w in self.sets:
+            if not w.busy:
+                w.busy = True
+                return w
+        w = _Workspace()
+        w.busy = True
+        self.sets.append(w)
+        return w
+
+
+class _CallState(dict):
+    """Everything one forward leaves for its backward.  Gives the workspace back when backward has
+    run, or when the graph is dropped without one."""
+
+    def release(self):
+        ws = self.pop('ws', None)
+        if ws is not None:
+            ws.busy = False
+
+    def __del__(self):
+        self.release()
 
 
 class _ExecFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, plan, need_grad, *params):
         ctx.net = net
-        ctx.state = net._run_forward(x, plan, need_grad)
-        return ctx.state['logits']
+        st = net._run_forward(x, plan, need_grad)
+        # the output must not stay reachable from ctx: output -> grad_fn -> ctx -> state -> output is
+        # a reference cycle that only the cyclic GC frees, and GBs of arena would pile up meanwhile
+        logits = st.pop('logits')
+        if need_grad:
+            ctx.state = st
+        else:
+            st.release()
+            ctx.state = None
+        return logits
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -144,7 +193,7 @@ class ModuleNet(nn.Module):
         self._tokens = [i2t[i] for i in range(len(i2t))]
         self._binary = [V.get_num_inputs(t) == 2 for t in self._tokens]
         self._fc_idx = [i for i, m in enumerate(self.classifier) if isinstance(m, nn.Linear)]
-        self._ws = _Workspace()
+        self._pool = _WorkspacePool()
         self._packed_key = None
         self._packed = {}
         self.used_fns = None
@@ -275,8 +324,8 @@ class ModuleNet(nn.Module):
         if x.dim() != 4 or tuple(x.shape[1:]) != (d['cin'], 14, 14):
             raise ValueError('features must be [N, %d, 14, 14]' % d['cin'])
         pk = self._pack_weights(dev)
-        ws, info = self._ws, plan.info
-        st = {'plan': plan, 'N': N, 'pk': pk}
+        ws, info = self._pool.acquire(), plan.info
+        st = _CallState(plan=plan, N=N, pk=pk, ws=ws)
         blob_host = torch.from_numpy(plan.blob())
         st['blob'] = ws.get('blob', blob_host.numel(), torch.int32, dev)
         st['blob'].copy_(blob_host)
@@ -359,7 +408,7 @@ class ModuleNet(nn.Module):
         d = self._dims
         plan, pk, N = st['plan'], st['pk'], st['N']
         dev = dlogits.device
-        ws, lib = self._ws, _lib.load()
+        ws, lib = st['ws'], _lib.load()
         c, p_, cpad, nv = d['c'], d['p'], d['cin_pad'], len(self._tokens)
         np128, np64 = _rup(N, 128), _rup(N, 64)
         arena, blob, acts = st['arena'], st['blob'], st['acts']
@@ -468,4 +517,6 @@ class ModuleNet(nn.Module):
             out.append(gr if p.requires_grad else None)
         if self.backward_done_hook is not None:
             self.backward_done_hook()
+        if not self.keep_state:
+            st.release()
         return out
