@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 #pragma unroll
                 for (int i = 0; i < 7; i++) {
                     const int e = tid + 256 * (i0 + i), pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
-                    v[i] = *(const uint4*)(sp + (int64_t)pix * p.src_pix_stride * 2 + pc * 16);
+                    if (p.flags & 0x400) v[i] = make_uint4(e, pix, pc, 0);   // diagnostic: no source loads
+                    else v[i] = *(const uint4*)(sp + (int64_t)pix * p.src_pix_stride * 2 + pc * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < 7; i++) {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
                 // refill this ring slot for K-step s+4 (three K-steps of MFMAs hide the L2 latency)
-                const int sn = min(s + 4, nsteps - 1);
+                const int sn = (p.flags & 0x200) ? 0 : min(s + 4, nsteps - 1);   // 0x200: diagnostic, re-read step 0
                 wr[ks][0] = *(const bf16x8*)(wbase + sn * wstep);
                 wr[ks][1] = *(const bf16x8*)(wbase + sn * wstep + 1024);
                 __builtin_amdgcn_sched_barrier(0);   // keep the refill here: sunk to the loop end it is waited on at once
@@ -140,8 +141,18 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         }
     }
 
-    // epilogue: lane holds pixel (m, l15), channels ntile*128 + wave*32 + n*16 + lq*4 + 0..3
-    if (l15 >= 14) return;
+    // Epilogue.  A lane holds pixel (m, l15) x 4 channels, i.e. 8-byte pieces scattered over 14 cache
+    // lines per instruction; written, or worse read (residual, mask), that way the epilogue costs
+    // more than the K loop.  So the accumulators go through LDS (fp32, 7 image rows at a time, the
+    // halo image is dead by now) and come back pixel-major: every global access below is 16 bytes
+    // per lane, 1 KiB contiguous per wave.
+    if (p.flags & 0x100) {   // diagnostic: skip the epilogue
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; m++) sum += acc[m][0][0] + acc[m][1][1];
+        if (sum == 12345.678f) ((float*)p.dst)[tid] = sum;
+        return;
+    }
     int dslot, mslot, choff;
     if (p.pair_out > 0) {
         const int which = ntile / p.pair_out;
@@ -149,37 +160,78 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         mslot = which ? t.mask1 : t.mask0;
         choff = (ntile % p.pair_out) * 128;
     } else { dslot = t.dst0; mslot = t.mask0; choff = ntile * 128; }
-    if (dslot < 0) return;
-    const int64_t dbase = (int64_t)dslot * p.dst_slot_stride + choff;
-    const int64_t rbase = (int64_t)t.res * p.dst_slot_stride + choff;
-    const int64_t mbase = (int64_t)mslot * p.dst_slot_stride + choff;
+    if (dslot < 0) return;     // uniform over the workgroup
     const bool has_res = t.res >= 0, has_mask = mslot >= 0;
     const bool has_bias = (p.flags & VQA_CONV_BIAS) != 0, relu = (p.flags & VQA_CONV_RELU) != 0;
     const float* bias = p.bias + (int64_t)t.wgroup * p.n_out + ntile * 128;
+    const char* rsrc = (const char*)p.res + ((int64_t)t.res * p.dst_slot_stride + choff) * 2;
+    const char* msrc = (const char*)p.mask + ((int64_t)mslot * p.dst_slot_stride + choff) * 2;
+    char* dptr = (char*)p.dst + ((int64_t)dslot * p.dst_slot_stride + choff) * 2;
+    float4 bv[2];
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int ch = wave * 32 + n * 16 + lq * 4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_bias) bv = *(const float4*)(bias + ch);
+    for (int n = 0; n < 2; n++)
+        bv[n] = has_bias ? *(const float4*)(bias + wave * 32 + n * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* stg = (float*)halo;          // [98 pixels][132 floats]: 528-byte rows keep the writes conflict-free
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        // this thread's 16-byte pieces of the half: piece e -> pixel 98*half + (e >> 4), channels 8*(e & 15)..+7
+        uint4 rv[7], mv[7];
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
-            const int pix = m * 14 + l15;
-            const int64_t off = (int64_t)pix * p.dst_pix_stride + ch;
-            float o0 = acc[m][n][0] + bv.x, o1 = acc[m][n][1] + bv.y;
-            float o2 = acc[m][n][2] + bv.z, o3 = acc[m][n][3] + bv.w;
-            if (has_res) {
-                const u16x4 r = *(const u16x4*)((const bf16_t*)p.res + rbase + off);
-                o0 += bf2f(r[0]); o1 += bf2f(r[1]); o2 += bf2f(r[2]); o3 += bf2f(r[3]);
+        for (int i = 0; i < 7; i++) {
+            const int e = tid + 256 * i, pl = min(e >> 4, 97), pc = e & 15;
+            const int64_t goff = ((int64_t)(98 * half + pl) * p.dst_pix_stride + pc * 8) * 2;
+            if (has_res) rv[i] = *(const uint4*)(rsrc + goff);
+            if (has_mask) mv[i] = *(const uint4*)(msrc + goff);
+        }
+        __syncthreads();     // K loop reads (half 0) / previous half's staging reads are done
+        if (l15 < 14) {
+#pragma unroll
+            for (int mm = 0; mm < 7; mm++) {
+                const int m = half * 7 + mm;      // static after unrolling both halves? no: select below
+                f32x4 a0 = half ? acc[7 + mm][0] : acc[mm][0];
+                f32x4 a1 = half ? acc[7 + mm][1] : acc[mm][1];
+                float* row = stg + (mm * 14 + l15) * 132 + wave * 32 + lq * 4;
+                *(float4*)(row) = make_float4(a0[0] + bv[0].x, a0[1] + bv[0].y, a0[2] + bv[0].z, a0[3] + bv[0].w);
+                *(float4*)(row + 16) = make_float4(a1[0] + bv[1].x, a1[1] + bv[1].y, a1[2] + bv[1].z, a1[3] + bv[1].w);
+                (void)m;
             }
-            if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
-            if (has_mask) {
-                const u16x4 k = *(const u16x4*)((const bf16_t*)p.mask + mbase + off);
-                // bf16 bits > 0 as a signed value <=> positive finite/inf (zero and negatives fail)
-                o0 = ((int16_t)k[0] > 0) ? o0 : 0.f; o1 = ((int16_t)k[1] > 0) ? o1 : 0.f;
-                o2 = ((int16_t)k[2] > 0) ? o2 : 0.f; o3 = ((int16_t)k[3] > 0) ? o3 : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int e = tid + 256 * i, pl = e >> 4, pc = e & 15;
+            if (pl < 98) {
+                const float4 f0 = *(const float4*)(stg + pl * 132 + pc * 8);
+                const float4 f1 = *(const float4*)(stg + pl * 132 + pc * 8 + 4);
+                float o[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                if (has_res) {
+                    const uint32_t r[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        o[2 * j] += __uint_as_float(r[j] << 16);
+                        o[2 * j + 1] += __uint_as_float(r[j] & 0xFFFF0000u);
+                    }
+                }
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) o[j] = fmaxf(o[j], 0.f);
+                }
+                if (has_mask) {
+                    // a bf16 is positive iff its 16 bits, read as a signed integer, are > 0
+                    const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        o[2 * j] = ((int16_t)(k[j] & 0xFFFF) > 0) ? o[2 * j] : 0.f;
+                        o[2 * j + 1] = ((int16_t)(k[j] >> 16) > 0) ? o[2 * j + 1] : 0.f;
+                    }
+                }
+                uint4 ov;
+                ov.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+                ov.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+                ov.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+                ov.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+                *(uint4*)(dptr + ((int64_t)(98 * half + pl) * p.dst_pix_stride + pc * 8) * 2) = ov;
             }
-            u16x4 o = {f2bf(o0), f2bf(o1), f2bf(o2), f2bf(o3)};
-            *(u16x4*)((bf16_t*)p.dst + dbase + off) = o;
         }
     }
 }
@@ -187,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stream) {
     if (!p || !p->src || !p->dst || !p->w || !p->tiles || (taps != 9 && taps != 1) ||
         p->k_chunks <= 0 || p->n_out <= 0 || p->n_out % 128 != 0 || p->num_tiles < 0 ||
-        p->src_pix_stride % 8 != 0 || p->dst_pix_stride % 4 != 0 ||
+        p->src_pix_stride % 8 != 0 || p->dst_pix_stride % 8 != 0 ||
         ((p->flags & VQA_CONV_BIAS) && !p->bias)) {
         vqa_set_error("vqa_conv_tiles: bad argument");
         return VQA_EINVAL;
