@@ -83,10 +83,12 @@ int parse_row(const int64_t* row, int T, const int8_t* arity, int V, int null_id
     }
 }
 
-void push_tile(std::vector<int32_t>& b, int s0, int s1, int d0, int d1, int res, int m0, int m1,
-               int wg) {
-    const int32_t t[8] = {s0, s1, d0, d1, res, m0, m1, wg};
-    b.insert(b.end(), t, t + 8);
+inline void push_tile(std::vector<int32_t>& b, int s0, int s1, int d0, int d1, int res, int m0, int m1,
+                      int wg) {
+    const size_t at = b.size();
+    b.resize(at + 8);            // capacity is reserved up front: no reallocation here
+    int32_t* t = b.data() + at;
+    t[0] = s0; t[1] = s1; t[2] = d0; t[3] = d1; t[4] = res; t[5] = m0; t[6] = m1; t[7] = wg;
 }
 
 }  // namespace
@@ -104,6 +106,8 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
     if (!pl) { vqa_set_error("out of host memory"); return VQA_EINVAL; }
     pl->N = N; pl->T = T; pl->C = C; pl->V = V;
     pl->used.assign((size_t)N * T, 0.0f);
+    pl->nodes.reserve((size_t)N * (T + 1));
+    pl->roots.reserve(N);
     for (int i = 0; i < N; i++) {
         pl->pending.clear();
         int rc = parse_row(programs + (size_t)i * T, T, arity, V, null_id, start_id, scene_id, i,
@@ -138,11 +142,23 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
 
     // level buckets: nodes of a level sorted by (token, node id)
     pl->level_nodes.assign(pl->num_levels, {});
+    {
+        std::vector<int> cnt(pl->num_levels, 0);
+        for (int v = 0; v < NV; v++) cnt[pl->nodes[v].level]++;
+        for (int L = 0; L < pl->num_levels; L++) pl->level_nodes[L].reserve(cnt[L]);
+    }
     for (int v = 0; v < NV; v++) pl->level_nodes[pl->nodes[v].level].push_back(v);
-    for (auto& lv : pl->level_nodes)
-        std::stable_sort(lv.begin(), lv.end(), [&](int a, int b) {
-            return pl->nodes[a].token < pl->nodes[b].token;
-        });
+    {   // stable counting sort of each level by token
+        std::vector<int> start(V + 1), tmp;
+        for (auto& lv : pl->level_nodes) {
+            std::fill(start.begin(), start.end(), 0);
+            for (int v : lv) start[pl->nodes[v].token + 1]++;
+            for (int t = 0; t < V; t++) start[t + 1] += start[t];
+            tmp.resize(lv.size());
+            for (int v : lv) tmp[start[pl->nodes[v].token]++] = v;
+            lv.swap(tmp);
+        }
+    }
 
     auto in_slot = [&](int v) {   // slot the residual body of node v reads
         const PlanNode& nd = pl->nodes[v];
@@ -152,6 +168,7 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
     };
 
     std::vector<int32_t>& b = pl->blob;
+    b.reserve((size_t)NV * 56 + (size_t)N * 64 + (size_t)nb * 24 + 1024);
     pl->levels.assign(pl->num_levels, {});
     int max_tiles = 0;
     for (int L = 0; L < pl->num_levels; L++) {

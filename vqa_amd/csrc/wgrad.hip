@@ -112,13 +112,26 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
 #pragma unroll
             for (int o = 0; o < 4; o++)
                 bf[o] = frag_from_tr(lds_tr4(db + o * 32), lds_tr4(db + o * 32 + 8 * DY_STRIDE));
+            // taps run through a 3-deep ring of source fragments fetched two taps ahead, and the issue
+            // order is pinned (2 LDS reads : 4 MFMAs); otherwise every tap waits for its own reads
+            auto afrag = [&](int t) {
+                const int tapoff = (TAPS == 9) ? ((t / 3) * 16 + (t % 3)) : 17;
+                return frag_from_tr(lds_tr4(xb + tapoff * XH_STRIDE), lds_tr4(xb + (tapoff + 8) * XH_STRIDE));
+            };
+            bf16x8 ar[3];
+            ar[0] = afrag(0);
+            if (TAPS > 1) ar[1] = afrag(1);
 #pragma unroll
             for (int t = 0; t < TAPS; t++) {
-                const int tapoff = (TAPS == 9) ? ((t / 3) * 16 + (t % 3)) : 17;
-                const bf16x8 af = frag_from_tr(lds_tr4(xb + tapoff * XH_STRIDE),
-                                               lds_tr4(xb + (tapoff + 8) * XH_STRIDE));
+                if (t + 2 < TAPS) ar[(t + 2) % 3] = afrag(t + 2);
 #pragma unroll
-                for (int o = 0; o < 4; o++) acc[t][o] = mma16(af, bf[o], acc[t][o]);
+                for (int o = 0; o < 4; o++) acc[t][o] = mma16(ar[t % 3], bf[o], acc[t][o]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, TAPS > 1 ? 12 : 10, 0);
+#pragma unroll
+            for (int t = 0; t < TAPS; t++) {
+                if (t + 2 < TAPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
     }

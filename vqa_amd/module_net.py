@@ -53,6 +53,7 @@ class _Workspace:
     def __init__(self):
         self.bufs = {}
         self.busy = False
+        self.blob_event = None
 
     def get(self, name, numel, dtype, device, zero=False):
         t = self.bufs.get(name)
@@ -195,6 +196,7 @@ class ModuleNet(nn.Module):
         self._fc_idx = [i for i, m in enumerate(self.classifier) if isinstance(m, nn.Linear)]
         self._pool = _WorkspacePool()
         self._packed_key = None
+        self._packed_stale = False
         self._packed = {}
         self.used_fns = None
         self.wgrad_chunk = 16
@@ -223,9 +225,13 @@ class ModuleNet(nn.Module):
     def _pack_weights(self, device):
         """bf16 LDS-image copies of all weights; redone only when a parameter changed."""
         plist = self._param_groups()
+        # Version counters catch in-place edits and load_state_dict, but torch's fused optimizers
+        # update parameters without bumping them, so a backward pass (after which an optimizer step
+        # is to be expected) also marks the packed copies stale.
         key = tuple((p.data_ptr(), p._version) for _, p in plist) + (str(device),)
-        if key == self._packed_key:
+        if key == self._packed_key and not self._packed_stale:
             return self._packed
+        self._packed_stale = False
         d = self._dims
         c, p_, cin, cpad = d['c'], d['p'], d['cin'], d['cin_pad']
         nv = len(self._tokens)
@@ -326,9 +332,18 @@ class ModuleNet(nn.Module):
         pk = self._pack_weights(dev)
         ws, info = self._pool.acquire(), plan.info
         st = _CallState(plan=plan, N=N, pk=pk, ws=ws)
-        blob_host = torch.from_numpy(plan.blob())
-        st['blob'] = ws.get('blob', blob_host.numel(), torch.int32, dev)
-        st['blob'].copy_(blob_host)
+        nb = info.blob_words
+        host = ws.bufs.get('blob_host')
+        if host is None or host.numel() < nb:
+            host = ws.bufs['blob_host'] = torch.empty(nb + nb // 4, dtype=torch.int32, pin_memory=True)
+            ws.blob_event = None
+        if ws.blob_event is not None:
+            ws.blob_event.synchronize()      # the previous upload from this pinned buffer has left the host
+        plan.blob_into(host)
+        st['blob'] = ws.get('blob', nb, torch.int32, dev)
+        st['blob'].copy_(host[:nb], non_blocking=True)
+        ws.blob_event = torch.cuda.Event()
+        ws.blob_event.record()
         slots = info.slots_total if need_grad else info.slots_fwd
         st['arena'] = arena = ws.get('arena', slots * HW * c, torch.bfloat16, dev)
         xs = x.detach().to(torch.float32).contiguous()
@@ -515,6 +530,7 @@ class ModuleNet(nn.Module):
                 if self.grad_ready_hook is not None and name not in emitted:
                     self.grad_ready_hook(name, gr)
             out.append(gr if p.requires_grad else None)
+        self._packed_stale = True
         if self.backward_done_hook is not None:
             self.backward_done_hook()
         if not self.keep_state:

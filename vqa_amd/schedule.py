@@ -75,6 +75,11 @@ class Plan:
         _lib.check(self._lib.vqa_plan_blob(self._h, out.ctypes.data_as(_lib.i32p)))
         return out
 
+    def blob_into(self, host_tensor):
+        """Write the blob into a caller-provided int32 host tensor (e.g. pinned memory)."""
+        assert host_tensor.numel() >= self.info.blob_words
+        _lib.check(self._lib.vqa_plan_blob(self._h, C.cast(host_tensor.data_ptr(), _lib.i32p)))
+
     def section(self, name):
         off, cnt = C.c_int32(), C.c_int32()
         _lib.check(self._lib.vqa_plan_section(self._h, _lib.SEC[name], C.byref(off), C.byref(cnt)))
