@@ -87,6 +87,8 @@ def main():
     net = ModuleNet(False, vocab, module_dim=a.module_dim)
     net.load_state_dict(synth.synth_state_dict(17, vocab, module_dim=a.module_dim))   # identical replicas
     net.to(dev).train()
+    if os.environ.get('VQA_WGRAD_CHUNK'):
+        net.wgrad_chunk = int(os.environ['VQA_WGRAD_CHUNK'])
     step_net = net
     if world > 1:
         from vqa_amd.dp import DataParallelExecutor

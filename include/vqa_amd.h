@@ -141,6 +141,28 @@ typedef struct {
 
 int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps /* 9 or 1 */, void* stream);
 
+/* Fused residual body for module width 128: both 3x3 convolutions of one map in one workgroup
+ * (Layers.py:33-36 / Module_Model.py:47-50 forward; their input gradients backward).  Tile fields:
+ * src0 = input map, dst1 = intermediate map (conv1 output H, or dH), mask1 = mask of the
+ * intermediate (backward: H) or -1, dst0 = final map, res = residual of the final map or -1,
+ * mask0 = mask of the final map or -1.  All maps are slots of one arena, 256-byte pixels.
+ *   intermediate = [relu](first(src) + bias_first) * (mask1 > 0)
+ *   final        = [relu](second(intermediate) + bias_second + res) * (mask0 > 0) */
+typedef struct {
+    void* arena;
+    const void* w_first;        /* packed weights of the first convolution, one group per token */
+    const void* w_second;
+    const float* bias_first;    /* fp32 [groups][128] or null */
+    const float* bias_second;
+    const vqa_conv_tile* tiles; /* device */
+    int64_t slot_stride;        /* elements between slots (196 * 128) */
+    int64_t w_group_stride;     /* elements between weight groups (9 * 128 * 128) */
+    int32_t flags;              /* VQA_CONV_BIAS | VQA_CONV_RELU, applied to both convolutions */
+    int32_t num_tiles;
+} vqa_resblock_params;
+
+int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);
+
 /* Weight packing: fp32 tensor -> bf16 image the conv kernel DMA-copies into LDS.
  * Source element (n, k, t) is at w[group*g_stride + n*n_stride + k*k_stride + (flip ? taps-1-t : t)]
  * (forward: n = out channel, k = in channel; input-gradient: swapped and flipped). */
@@ -257,7 +279,13 @@ typedef struct {
     float *g_conv1, *g_conv2, *g_proj;          /* fp32 accumulators [V][9][C][C], [V][2C][C] */
     float *gb_conv1, *gb_conv2, *gb_proj;       /* fp32 [V][C] */
     int32_t C, V;
+    int32_t flags;                     /* VQA_TREE_* */
+    int32_t reserved;
 } vqa_tree_ctx;
+
+/* vqa_tree_ctx.flags: run the residual body as two vqa_conv_tiles launches even where the fused
+ * vqa_resblock_tiles kernel applies (C == 128); same results, for comparison and timing. */
+#define VQA_TREE_UNFUSED 1
 
 int vqa_tree_forward(const vqa_plan* plan, const vqa_tree_ctx* ctx, void* stream);
 /* input gradients level by level, scene fan-in, then all weight gradients */

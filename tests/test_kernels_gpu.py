@@ -123,6 +123,62 @@ def test_conv_dgrad_with_mask_and_residual():
     close(from_slots(arena[3 * S:], C), ref)
 
 
+@pytest.mark.parametrize('backward', [False, True])
+def test_resblock_fused_matches_two_launches_and_torch(backward):
+    """vqa_resblock_tiles (both 3x3 convolutions of a residual body in one workgroup) gives the same
+    bits as two vqa_conv_tiles launches, and both match torch to bf16 rounding.  The backward
+    form masks the intermediate map by a stored activation and the result by another."""
+    from vqa_amd import ops
+    C, G, S = 128, 3, 9
+    x = bf(rnd((S, C, 14, 14), 41))
+    w1 = bf(rnd((G, C, C, 3, 3), 42, 0.04))
+    w2 = bf(rnd((G, C, C, 3, 3), 43, 0.04))
+    b1, b2 = rnd((G, C), 44, 0.1), rnd((G, C), 45, 0.1)
+    hmask = bf(F.relu(rnd((S, C, 14, 14), 46)))
+    omask = bf(F.relu(rnd((S, C, 14, 14), 47)))
+    groups = [0, 2, 1, 1, 0, 2, 2, 0, 1]
+    zeros = torch.zeros(S, HW, C, dtype=torch.bfloat16, device=dev())
+    # slots: x | hmask | omask | mid(fused) | out(fused) | mid(two) | out(two)
+    arena = torch.cat([to_slots(x), to_slots(hmask), to_slots(omask), zeros, zeros, zeros, zeros])
+    if backward:
+        p1 = ops.pack_conv_weight(w1.to(dev()), G, C, C, 9, C * C * 9, 9, C * 9, flip=True)
+        p2 = ops.pack_conv_weight(w2.to(dev()), G, C, C, 9, C * C * 9, 9, C * 9, flip=True)
+        bias1 = bias2 = None
+        m1 = lambda i: S + i
+        m0 = lambda i: (2 * S + i) if i % 3 else -1       # some tiles without a final mask
+    else:
+        p1 = ops.pack_conv_weight(w1.to(dev()), G, C, C, 9, C * C * 9, C * 9, 9)
+        p2 = ops.pack_conv_weight(w2.to(dev()), G, C, C, 9, C * C * 9, C * 9, 9)
+        bias1, bias2 = b1.to(dev()), b2.to(dev())
+        m1 = m0 = lambda i: -1
+    fused = tiles_tensor([[i, -1, 4 * S + i, 3 * S + i, i, m0(i), m1(i), groups[i]] for i in range(S)])
+    ops.resblock_tiles(arena, p1, p2, fused, S, bias_first=bias1, bias_second=bias2, relu=not backward)
+    first = tiles_tensor([[i, -1, 5 * S + i, -1, -1, m1(i), -1, groups[i]] for i in range(S)])
+    second = tiles_tensor([[5 * S + i, -1, 6 * S + i, -1, i, m0(i), -1, groups[i]] for i in range(S)])
+    geo = dict(taps=9, k_chunks=1, n_out=C, src_slot_stride=HW * C, dst_slot_stride=HW * C,
+               src_pix_stride=C, dst_pix_stride=C, w_group_stride=9 * C * C, relu=not backward)
+    ops.conv_tiles(arena, arena, p1, first, S, bias=bias1, mask=arena, **geo)
+    ops.conv_tiles(arena, arena, p2, second, S, bias=bias2, res=arena, mask=arena, **geo)
+    torch.cuda.synchronize()
+    assert torch.equal(arena[3 * S:4 * S], arena[5 * S:6 * S])
+    assert torch.equal(arena[4 * S:5 * S], arena[6 * S:7 * S])
+    mid_ref, out_ref = [], []
+    for i in range(S):
+        g = groups[i]
+        if backward:
+            mid = bf(F.conv_transpose2d(x[i:i + 1], w1[g], padding=1)[0] * (hmask[i] > 0))
+            out = F.conv_transpose2d(mid[None], w2[g], padding=1)[0] + x[i]
+            if m0(i) >= 0:
+                out = out * (omask[i] > 0)
+        else:
+            mid = bf(F.relu(F.conv2d(x[i:i + 1], w1[g], b1[g], padding=1)[0]))
+            out = F.relu(F.conv2d(mid[None], w2[g], b2[g], padding=1)[0] + x[i])
+        mid_ref.append(mid)
+        out_ref.append(out)
+    close(from_slots(arena[3 * S:4 * S], C), torch.stack(mid_ref))
+    close(from_slots(arena[4 * S:5 * S], C), torch.stack(out_ref), tol=2e-2)
+
+
 def test_conv1x1_dgrad_pair_out():
     """proj input gradient: 256 outputs split over two destination maps with separate masks."""
     from vqa_amd import ops

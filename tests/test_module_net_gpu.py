@@ -110,6 +110,32 @@ def test_small_model_sampler_programs_batch_70(vocab):
     check_pair(*run_pair(vocab, dims, prog, x, ans, 11))
 
 
+def test_fused_and_two_launch_residual_body_identical(vocab):
+    """Width-128 modules run their two convolutions in one kernel by default; the two-launch path
+    (the one wider modules use) must give the same bits for logits and every gradient."""
+    from vqa_amd.module_net import ModuleNet
+    dims = small_dims(128)
+    sd = synth.synth_state_dict(21, vocab, **dims)
+    prog = torch.from_numpy(synth.synth_programs(22, 40, vocab, max_len=14, max_nodes=12)).cuda()
+    x = torch.from_numpy(synth.synth_features(22, 40, dims['feature_dim'])).cuda()
+    ans = torch.from_numpy(synth.synth_answers(22, 40)).cuda()
+    out = []
+    for fuse in (True, False):
+        net = ModuleNet(False, vocab, **dims)
+        net.load_state_dict(sd)
+        net.cuda().train()
+        net.fuse_residual_body = fuse
+        logits = net(x, prog)
+        F.cross_entropy(logits, ans).backward()
+        torch.cuda.synchronize()
+        out.append((logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert torch.equal(out[0][0], out[1][0])
+    assert out[0][1].keys() == out[1][1].keys()
+    # weight gradients are accumulated with fp32 atomics (order varies run to run): tight, not bitwise
+    for k in out[0][1]:
+        assert rel(out[0][1][k], out[1][1][k]) <= 1e-5, k
+
+
 def test_second_step_and_eval_forward_between(vocab):
     """A no-grad forward between a training forward and its backward must not disturb it, and a
     weight update must be picked up by the next forward (packed copies refresh)."""

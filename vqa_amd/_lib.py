@@ -49,7 +49,13 @@ class TreeCtx(C.Structure):
                 ('b_conv1', vp), ('b_conv2', vp), ('b_proj', vp),
                 ('g_conv1', vp), ('g_conv2', vp), ('g_proj', vp),
                 ('gb_conv1', vp), ('gb_conv2', vp), ('gb_proj', vp),
-                ('C', i32), ('V', i32)]
+                ('C', i32), ('V', i32), ('flags', i32), ('reserved', i32)]
+
+
+class ResblockParams(C.Structure):
+    _fields_ = [('arena', vp), ('w_first', vp), ('w_second', vp), ('bias_first', vp),
+                ('bias_second', vp), ('tiles', vp), ('slot_stride', i64), ('w_group_stride', i64),
+                ('flags', i32), ('num_tiles', i32)]
 
 
 SEC = {name: i for i, name in enumerate((
@@ -59,6 +65,7 @@ SEC = {name: i for i, name in enumerate((
     'WG_PITEMS', 'WG_PSRC0', 'WG_PSRC1', 'WG_PDY'))}
 
 CONV_BIAS, CONV_RELU = 1, 2
+TREE_UNFUSED = 1
 
 # name -> (restype, argtypes); every symbol include/vqa_amd.h declares
 SIGNATURES = {
@@ -77,6 +84,7 @@ SIGNATURES = {
     'vqa_plan_section': (i32, [vp, i32, i32p, i32p]),
     'vqa_plan_slot': (i32, [vp, i32, i32]),
     'vqa_conv_tiles': (i32, [C.POINTER(ConvParams), i32, vp]),
+    'vqa_resblock_tiles': (i32, [C.POINTER(ResblockParams), vp]),
     'vqa_pack_conv_weight': (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp]),
     'vqa_wgrad_tiles': (i32, [C.POINTER(WgradParams), i32, vp]),
     'vqa_unpack_conv_grad': (i32, [vp, vp, i32, i32, i32, i32, i64, vp]),

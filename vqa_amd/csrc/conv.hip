@@ -27,6 +27,163 @@
 #define CONV_LDS HALO_BYTES
 #define MT 14                                 // pixel tiles = image rows
 
+// ---------------------------------------------------------------------------------------------
+// Building blocks shared by the single-conv kernel and the fused residual-body kernel
+// ---------------------------------------------------------------------------------------------
+
+// zero the border of the halo image (interior positions are overwritten by every staging pass)
+__device__ __forceinline__ void halo_zero_border(char* halo, int tid) {
+    for (int idx = tid; idx < HALO_POS * 16; idx += 256) {
+        const int pos = idx >> 4, row = pos >> 4, col = pos & 15;
+        if (row == 0 || row >= 15 || col == 0 || col == 15)
+            *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+    }
+}
+
+// copy one 128-channel chunk of a source map (196 pixels x 256 B) into the halo image interior,
+// through registers, 7 16-byte pieces per thread at a time
+__device__ __forceinline__ void halo_stage(char* halo, const char* sp, int pix_stride_bytes, int tid, bool diag_noload) {
+#pragma unroll 1
+    for (int i0 = 0; i0 < 14; i0 += 7) {
+        uint4 v[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int e = tid + 256 * (i0 + i), pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
+            if (diag_noload) v[i] = make_uint4(e, pix, pc, 0);
+            else v[i] = *(const uint4*)(sp + (int64_t)pix * pix_stride_bytes + pc * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int e = tid + 256 * (i0 + i), pix = e >> 4, pc = e & 15;
+            if (pix < VQA_HW) {
+                const int y = pix / 14, x = pix - y * 14;
+                *(uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16) = v[i];
+            }
+        }
+    }
+}
+
+// K loop over one 128-channel chunk already staged in the halo image: TAPS x 4 K-steps x 14 pixel
+// tiles.  Weights come through the 4-slot register ring `wr` (refilled for K-step s+4 after use,
+// so three K-steps of MFMAs cover the L2 latency); pixel fragments through an 8-deep ring read 7
+// tiles ahead; the issue order is pinned to 1 LDS read : 2 MFMA (left alone, the scheduler collapses
+// the ring and waits on every read right after issuing it).
+template <int TAPS>
+__device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[MT], const char* wbase, int64_t wstep,
+                                           int nsteps, int& s, bf16x8 (&wr)[4][2], f32x4 (&acc)[MT][2], bool diag_now) {
+    bf16x8 xq[8];
+    {
+        const char* x0 = halo + ((TAPS == 9) ? 0 : 17) * HALO_STRIDE;
+#pragma unroll
+        for (int q = 0; q < 7; q++) xq[q] = *(const bf16x8*)(x0 + xaddr[q]);
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; tap++) {
+        const int tapoff = (TAPS == 9) ? ((tap / 3) * 16 + (tap % 3)) : 17;
+        const int tn = (tap + 1 < TAPS) ? tap + 1 : tap;      // last tap: harmless re-read
+        const int tapoff_n = (TAPS == 9) ? ((tn / 3) * 16 + (tn % 3)) : 17;
+        const char* xb = halo + tapoff * HALO_STRIDE;
+        const char* xn = halo + tapoff_n * HALO_STRIDE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++, s++) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const int q = ks * MT + m;            // 0..55 within the tap
+                const int qa = q + 7;                 // fragment to fetch now
+                const int ka = (qa / MT) & 3, ma = qa % MT;
+                xq[qa & 7] = *(const bf16x8*)((qa < 4 * MT ? xb : xn) + xaddr[ma] + ka * 64);
+                acc[m][0] = mma16(wr[ks][0], xq[q & 7], acc[m][0]);
+                acc[m][1] = mma16(wr[ks][1], xq[q & 7], acc[m][1]);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+            const int sn = diag_now ? 0 : min(s + 4, nsteps - 1);
+            wr[ks][0] = *(const bf16x8*)(wbase + sn * wstep);
+            wr[ks][1] = *(const bf16x8*)(wbase + sn * wstep + 1024);
+            __builtin_amdgcn_sched_barrier(0);   // keep the refill here: sunk to the loop end it is waited on at once
+        }
+    }
+}
+
+// Final epilogue.  A lane holds pixel (m, l15) x 4 channels, i.e. 8-byte pieces scattered over 14
+// cache lines per instruction; written, or worse read (residual, mask), that way the epilogue costs
+// more than the K loop.  So the accumulators go through LDS (fp32, 7 image rows at a time, the halo
+// image is dead by now) and come back pixel-major: every global access is 16 bytes per lane,
+// 1 KiB contiguous per wave.   out = [relu]( acc + bias + res ) * (mask > 0)
+__device__ __forceinline__ void conv_epilogue(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+                                              const char* rsrc, const char* msrc, char* dptr, int pix_stride,
+                                              int tid) {
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    float4 bv[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+        bv[n] = bias ? *(const float4*)(bias + wave * 32 + n * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* stg = (float*)halo;          // [98 pixels][132 floats]: 528-byte rows keep the writes conflict-free
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        // this thread's 16-byte pieces of the half: piece e -> pixel 98*half + (e >> 4), channels 8*(e & 15)..+7
+        uint4 rv[7], mv[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int e = tid + 256 * i, pl = min(e >> 4, 97), pc = e & 15;
+            const int64_t goff = ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2;
+            if (rsrc) rv[i] = *(const uint4*)(rsrc + goff);
+            if (msrc) mv[i] = *(const uint4*)(msrc + goff);
+        }
+        __syncthreads();     // K loop reads (half 0) / previous half's staging reads are done
+        if (l15 < 14) {
+#pragma unroll
+            for (int mm = 0; mm < 7; mm++) {
+                const f32x4 a0 = half ? acc[7 + mm][0] : acc[mm][0];
+                const f32x4 a1 = half ? acc[7 + mm][1] : acc[mm][1];
+                float* row = stg + (mm * 14 + l15) * 132 + wave * 32 + lq * 4;
+                *(float4*)(row) = make_float4(a0[0] + bv[0].x, a0[1] + bv[0].y, a0[2] + bv[0].z, a0[3] + bv[0].w);
+                *(float4*)(row + 16) = make_float4(a1[0] + bv[1].x, a1[1] + bv[1].y, a1[2] + bv[1].z, a1[3] + bv[1].w);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int e = tid + 256 * i, pl = e >> 4, pc = e & 15;
+            if (pl < 98) {
+                const float4 f0 = *(const float4*)(stg + pl * 132 + pc * 8);
+                const float4 f1 = *(const float4*)(stg + pl * 132 + pc * 8 + 4);
+                float o[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                if (rsrc) {
+                    const uint32_t r[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        o[2 * j] += __uint_as_float(r[j] << 16);
+                        o[2 * j + 1] += __uint_as_float(r[j] & 0xFFFF0000u);
+                    }
+                }
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) o[j] = fmaxf(o[j], 0.f);
+                }
+                if (msrc) {
+                    // a bf16 is positive iff its 16 bits, read as a signed integer, are > 0
+                    const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        o[2 * j] = ((int16_t)(k[j] & 0xFFFF) > 0) ? o[2 * j] : 0.f;
+                        o[2 * j + 1] = ((int16_t)(k[j] >> 16) > 0) ? o[2 * j + 1] : 0.f;
+                    }
+                }
+                uint4 ov;
+                ov.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+                ov.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+                ov.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+                ov.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+                *(uint4*)(dptr + ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2) = ov;
+            }
+        }
+    }
+}
+
 template <int TAPS>
 __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char halo[];
@@ -46,13 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         wr[i][0] = *(const bf16x8*)(wbase + i * wstep);
         wr[i][1] = *(const bf16x8*)(wbase + i * wstep + 1024);
     }
-
-    // zero the border of the halo image (interior positions are overwritten by every chunk)
-    for (int idx = tid; idx < HALO_POS * 16; idx += 256) {
-        const int pos = idx >> 4, row = pos >> 4, col = pos & 15;
-        if (row == 0 || row >= 15 || col == 0 || col == 15)
-            *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
-    }
+    halo_zero_border(halo, tid);
 
     f32x4 acc[MT][2];
 #pragma unroll
@@ -60,92 +211,24 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-
     // LDS byte offset of this lane's pixel in every pixel tile, at tap (-1,-1), K-chunk lq
+    // (lanes 14, 15 read halo padding; their results are discarded)
     int xaddr[MT];
 #pragma unroll
-    for (int m = 0; m < MT; m++) {
-        xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;   // lanes 14, 15 read halo padding; discarded
-    }
+    for (int m = 0; m < MT; m++) xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
 
     int s = 0;
     for (int c = 0; c < p.k_chunks; c++) {
-        {
-            int slot, choff;
-            if (p.pair_chunks > 0) { slot = (c / p.pair_chunks) ? t.src1 : t.src0; choff = (c % p.pair_chunks) * 128; }
-            else { slot = t.src0; choff = c * 128; }
-            const char* sp = (const char*)p.src + ((int64_t)slot * p.src_slot_stride + choff) * 2;
-            __syncthreads();   // every wave is done reading the previous chunk's image
-            // 196 pixels x 16 pieces of 16 B, staged through registers 7 pieces per thread at a time
-            // (more in flight would not fit beside the accumulators at two workgroups per CU)
-#pragma unroll 1
-            for (int i0 = 0; i0 < 14; i0 += 7) {
-                uint4 v[7];
-#pragma unroll
-                for (int i = 0; i < 7; i++) {
-                    const int e = tid + 256 * (i0 + i), pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
-                    if (p.flags & 0x400) v[i] = make_uint4(e, pix, pc, 0);   // diagnostic: no source loads
-                    else v[i] = *(const uint4*)(sp + (int64_t)pix * p.src_pix_stride * 2 + pc * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < 7; i++) {
-                    const int e = tid + 256 * (i0 + i), pix = e >> 4, pc = e & 15;
-                    if (pix < VQA_HW) {
-                        const int y = pix / 14, x = pix - y * 14;
-                        *(uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16) = v[i];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        // K loop of this chunk: taps x 4 K-steps x 14 pixel tiles.  The pixel fragments run through
-        // an 8-deep register ring, read 7 tiles ahead of the MFMAs that use them, so that LDS latency
-        // is covered even when this wave is alone on its SIMD.
-        bf16x8 xq[8];
-        {
-            const char* x0 = halo + ((TAPS == 9) ? 0 : 17) * HALO_STRIDE;
-#pragma unroll
-            for (int q = 0; q < 7; q++) xq[q] = *(const bf16x8*)(x0 + xaddr[q]);
-        }
-#pragma unroll 1
-        for (int tap = 0; tap < TAPS; tap++) {
-            const int tapoff = (TAPS == 9) ? ((tap / 3) * 16 + (tap % 3)) : 17;
-            const int tn = (tap + 1 < TAPS) ? tap + 1 : tap;      // last tap: harmless re-read
-            const int tapoff_n = (TAPS == 9) ? ((tn / 3) * 16 + (tn % 3)) : 17;
-            const char* xb = halo + tapoff * HALO_STRIDE;
-            const char* xn = halo + tapoff_n * HALO_STRIDE;
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++, s++) {
-#pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    const int q = ks * MT + m;            // 0..55 within the tap
-                    const int qa = q + 7;                 // fragment to fetch now
-                    const int ka = (qa / MT) & 3, ma = qa % MT;
-                    xq[qa & 7] = *(const bf16x8*)((qa < 4 * MT ? xb : xn) + xaddr[ma] + ka * 64);
-                    acc[m][0] = mma16(wr[ks][0], xq[q & 7], acc[m][0]);
-                    acc[m][1] = mma16(wr[ks][1], xq[q & 7], acc[m][1]);
-                }
-                // pin the issue order to one LDS read, two MFMAs, ... : left alone the scheduler
-                // collapses the ring and waits on every read right after issuing it
-#pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                }
-                // refill this ring slot for K-step s+4 (three K-steps of MFMAs hide the L2 latency)
-                const int sn = (p.flags & 0x200) ? 0 : min(s + 4, nsteps - 1);   // 0x200: diagnostic, re-read step 0
-                wr[ks][0] = *(const bf16x8*)(wbase + sn * wstep);
-                wr[ks][1] = *(const bf16x8*)(wbase + sn * wstep + 1024);
-                __builtin_amdgcn_sched_barrier(0);   // keep the refill here: sunk to the loop end it is waited on at once
-            }
-        }
+        int slot, choff;
+        if (p.pair_chunks > 0) { slot = (c / p.pair_chunks) ? t.src1 : t.src0; choff = (c % p.pair_chunks) * 128; }
+        else { slot = t.src0; choff = c * 128; }
+        const char* sp = (const char*)p.src + ((int64_t)slot * p.src_slot_stride + choff) * 2;
+        __syncthreads();   // every wave is done reading the previous chunk's image
+        halo_stage(halo, sp, p.src_pix_stride * 2, tid, (p.flags & 0x400) != 0);
+        __syncthreads();
+        conv_kloop<TAPS>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, (p.flags & 0x200) != 0);
     }
 
-    // Epilogue.  A lane holds pixel (m, l15) x 4 channels, i.e. 8-byte pieces scattered over 14 cache
-    // lines per instruction; written, or worse read (residual, mask), that way the epilogue costs
-    // more than the K loop.  So the accumulators go through LDS (fp32, 7 image rows at a time, the
-    // halo image is dead by now) and come back pixel-major: every global access below is 16 bytes
-    // per lane, 1 KiB contiguous per wave.
     if (p.flags & 0x100) {   // diagnostic: skip the epilogue
         float sum = 0.f;
 #pragma unroll
@@ -161,79 +244,128 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         choff = (ntile % p.pair_out) * 128;
     } else { dslot = t.dst0; mslot = t.mask0; choff = ntile * 128; }
     if (dslot < 0) return;     // uniform over the workgroup
-    const bool has_res = t.res >= 0, has_mask = mslot >= 0;
-    const bool has_bias = (p.flags & VQA_CONV_BIAS) != 0, relu = (p.flags & VQA_CONV_RELU) != 0;
-    const float* bias = p.bias + (int64_t)t.wgroup * p.n_out + ntile * 128;
-    const char* rsrc = (const char*)p.res + ((int64_t)t.res * p.dst_slot_stride + choff) * 2;
-    const char* msrc = (const char*)p.mask + ((int64_t)mslot * p.dst_slot_stride + choff) * 2;
+    const float* bias = (p.flags & VQA_CONV_BIAS) ? p.bias + (int64_t)t.wgroup * p.n_out + ntile * 128 : nullptr;
+    const char* rsrc = t.res >= 0 ? (const char*)p.res + ((int64_t)t.res * p.dst_slot_stride + choff) * 2 : nullptr;
+    const char* msrc = mslot >= 0 ? (const char*)p.mask + ((int64_t)mslot * p.dst_slot_stride + choff) * 2 : nullptr;
     char* dptr = (char*)p.dst + ((int64_t)dslot * p.dst_slot_stride + choff) * 2;
-    float4 bv[2];
+    conv_epilogue(halo, acc, bias, (p.flags & VQA_CONV_RELU) != 0, rsrc, msrc, dptr, p.dst_pix_stride, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused residual body (module width 128 only): two 3x3 convolutions of one map in one workgroup.
+//   forward :  H = relu(conv1(x) + b1);   Y  = relu(x + conv2(H) + b2)        (Layers.py:33-36)
+//   backward:  dH = dgrad2(dZ) * (H > 0); dX = (dgrad1(dH) + dZ) * (X > 0)
+// The intermediate map never makes a round trip: its accumulators are rounded to bf16 straight into
+// the halo image that the second convolution reads, and leave for HBM (it is needed again by the
+// backward pass / the weight gradients) as whole 256-byte rows from that image.  One launch per
+// tree level instead of two, one source load and one cold-start per node instead of two.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_params p) {
+    extern __shared__ __attribute__((aligned(16))) char halo[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const vqa_conv_tile t = p.tiles[blockIdx.x];
+    const int64_t slot_b = p.slot_stride * 2;       // bytes per slot; pixel stride is 256 B (C = 128)
+    char* arena = (char*)p.arena;
+
+    const int64_t wstep = 8 * 1024;
+    const int64_t wgroup_off = (int64_t)t.wgroup * p.w_group_stride * 2 + (int64_t)(wave * 2) * 1024 + lane * 16;
+    const char* wbase = (const char*)p.w_first + wgroup_off;
+    bf16x8 wr[4][2];
 #pragma unroll
-    for (int n = 0; n < 2; n++)
-        bv[n] = has_bias ? *(const float4*)(bias + wave * 32 + n * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float* stg = (float*)halo;          // [98 pixels][132 floats]: 528-byte rows keep the writes conflict-free
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-        // this thread's 16-byte pieces of the half: piece e -> pixel 98*half + (e >> 4), channels 8*(e & 15)..+7
-        uint4 rv[7], mv[7];
+    for (int i = 0; i < 4; i++) {
+        wr[i][0] = *(const bf16x8*)(wbase + i * wstep);
+        wr[i][1] = *(const bf16x8*)(wbase + i * wstep + 1024);
+    }
+    halo_zero_border(halo, tid);
+    f32x4 acc[MT][2];
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const int e = tid + 256 * i, pl = min(e >> 4, 97), pc = e & 15;
-            const int64_t goff = ((int64_t)(98 * half + pl) * p.dst_pix_stride + pc * 8) * 2;
-            if (has_res) rv[i] = *(const uint4*)(rsrc + goff);
-            if (has_mask) mv[i] = *(const uint4*)(msrc + goff);
+    for (int m = 0; m < MT; m++) {
+        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int xaddr[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
+
+    halo_stage(halo, arena + (int64_t)t.src0 * slot_b, 256, tid, false);
+    __syncthreads();
+    int s = 0;
+    conv_kloop<9>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+
+    // ---- first epilogue: accumulators -> bf16 -> the image the second convolution reads
+    wbase = (const char*)p.w_second + wgroup_off;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {           // second weight stream starts now, lands under the epilogue
+        wr[i][0] = *(const bf16x8*)(wbase + i * wstep);
+        wr[i][1] = *(const bf16x8*)(wbase + i * wstep + 1024);
+    }
+    const char* m1 = t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr;
+    char* d1 = arena + (int64_t)t.dst1 * slot_b;
+    uint4 mv[13];
+    if (m1) {
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int e = tid + 256 * i, pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
+            mv[i] = *(const uint4*)(m1 + pix * 256 + pc * 16);
         }
-        __syncthreads();     // K loop reads (half 0) / previous half's staging reads are done
-        if (l15 < 14) {
+    }
+    const bool relu1 = (p.flags & VQA_CONV_RELU) != 0;
+    const float* b1 = (p.flags & VQA_CONV_BIAS) ? p.bias_first + (int64_t)t.wgroup * 128 : nullptr;
+    __syncthreads();        // every wave has finished reading the source image
+    if (l15 < 14) {
 #pragma unroll
-            for (int mm = 0; mm < 7; mm++) {
-                const int m = half * 7 + mm;      // static after unrolling both halves? no: select below
-                f32x4 a0 = half ? acc[7 + mm][0] : acc[mm][0];
-                f32x4 a1 = half ? acc[7 + mm][1] : acc[mm][1];
-                float* row = stg + (mm * 14 + l15) * 132 + wave * 32 + lq * 4;
-                *(float4*)(row) = make_float4(a0[0] + bv[0].x, a0[1] + bv[0].y, a0[2] + bv[0].z, a0[3] + bv[0].w);
-                *(float4*)(row + 16) = make_float4(a1[0] + bv[1].x, a1[1] + bv[1].y, a1[2] + bv[1].z, a1[3] + bv[1].w);
-                (void)m;
-            }
-        }
-        __syncthreads();
+        for (int n = 0; n < 2; n++) {
+            const int ch = wave * 32 + n * 16 + lq * 4;
+            const float4 bv = b1 ? *(const float4*)(b1 + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const int e = tid + 256 * i, pl = e >> 4, pc = e & 15;
-            if (pl < 98) {
-                const float4 f0 = *(const float4*)(stg + pl * 132 + pc * 8);
-                const float4 f1 = *(const float4*)(stg + pl * 132 + pc * 8 + 4);
-                float o[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                if (has_res) {
-                    const uint32_t r[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        o[2 * j] += __uint_as_float(r[j] << 16);
-                        o[2 * j + 1] += __uint_as_float(r[j] & 0xFFFF0000u);
-                    }
-                }
-                if (relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) o[j] = fmaxf(o[j], 0.f);
-                }
-                if (has_mask) {
-                    // a bf16 is positive iff its 16 bits, read as a signed integer, are > 0
-                    const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        o[2 * j] = ((int16_t)(k[j] & 0xFFFF) > 0) ? o[2 * j] : 0.f;
-                        o[2 * j + 1] = ((int16_t)(k[j] >> 16) > 0) ? o[2 * j + 1] : 0.f;
-                    }
-                }
-                uint4 ov;
-                ov.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-                ov.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-                ov.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
-                ov.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
-                *(uint4*)(dptr + ((int64_t)(98 * half + pl) * p.dst_pix_stride + pc * 8) * 2) = ov;
+            for (int m = 0; m < MT; m++) {
+                float o0 = acc[m][n][0] + bv.x, o1 = acc[m][n][1] + bv.y, o2 = acc[m][n][2] + bv.z, o3 = acc[m][n][3] + bv.w;
+                if (relu1) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+                pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+                *(uint2*)(halo + ((m + 1) * 16 + l15 + 1) * HALO_STRIDE + ch * 2) = pk;
             }
         }
     }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    // row-wise pass over the image: apply the mask (backward), store the intermediate map coalesced
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int e = tid + 256 * i, pix = e >> 4, pc = e & 15;
+        if (pix < VQA_HW) {
+            const int y = pix / 14, x = pix - y * 14;
+            uint4* cell = (uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16);
+            uint4 v = *cell;
+            if (m1) {
+                const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
+                uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (!((int16_t)(k[j] & 0xFFFF) > 0)) w4[j] &= 0xFFFF0000u;
+                    if (!((int16_t)(k[j] >> 16) > 0)) w4[j] &= 0x0000FFFFu;
+                }
+                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                *cell = v;
+            }
+            *(uint4*)(d1 + pix * 256 + pc * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- second convolution from the image, then the staged epilogue
+    s = 0;
+    conv_kloop<9>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+    const float* b2 = (p.flags & VQA_CONV_BIAS) ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr;
+    const char* rsrc = t.res >= 0 ? arena + (int64_t)t.res * slot_b : nullptr;
+    const char* msrc = t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr;
+    conv_epilogue(halo, acc, b2, relu1, rsrc, msrc, arena + (int64_t)t.dst0 * slot_b, 128, tid);
 }
 
 extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stream) {
@@ -259,6 +391,27 @@ extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stre
     else hipLaunchKernelGGL(conv_tiles_kernel<1>, grid, block, CONV_LDS, (hipStream_t)stream, *p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_conv_tiles: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}
+
+extern "C" int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream) {
+    if (!p || !p->arena || !p->w_first || !p->w_second || !p->tiles || p->num_tiles < 0 ||
+        ((p->flags & VQA_CONV_BIAS) && (!p->bias_first || !p->bias_second))) {
+        vqa_set_error("vqa_resblock_tiles: bad argument");
+        return VQA_EINVAL;
+    }
+    if (p->num_tiles == 0) return VQA_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)resblock_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+        attr_set = true;
+    }
+    // two 3x3 convolutions of 128 -> 128 channels per tile
+    VqaProfScope prof(VQA_K_CONV9, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles,
+                      (double)p->num_tiles * VQA_HW * 2.0 * 128 * 3, (hipStream_t)stream);
+    hipLaunchKernelGGL(resblock_tiles_kernel, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_resblock_tiles: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;
 }
 

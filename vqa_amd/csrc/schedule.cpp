@@ -168,7 +168,7 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
     };
 
     std::vector<int32_t>& b = pl->blob;
-    b.reserve((size_t)NV * 56 + (size_t)N * 64 + (size_t)nb * 24 + 1024);
+    b.reserve((size_t)NV * 72 + (size_t)N * 64 + (size_t)nb * 24 + 1024);
     pl->levels.assign(pl->num_levels, {});
     int max_tiles = 0;
     for (int L = 0; L < pl->num_levels; L++) {
@@ -208,6 +208,19 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
             else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
             else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
             push_tile(b, pl->slot_dH + v, -1, dst, -1, pl->slot_dZ + v, mask, -1, nd.token);
+        }
+        // the same four passes as two fused tiles per node: forward (x -> H -> Y), backward (dZ -> dH -> dX)
+        lv.off_fused_fwd = (int)b.size();
+        for (int v : nodes)
+            push_tile(b, in_slot(v), -1, pl->slot_Y + v, pl->slot_H + v, in_slot(v), -1, -1, pl->nodes[v].token);
+        lv.off_fused_bwd = (int)b.size();
+        for (int v : nodes) {
+            const PlanNode& nd = pl->nodes[v];
+            int dst, mask;
+            if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
+            else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
+            else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
+            push_tile(b, pl->slot_dZ + v, -1, dst, pl->slot_dH + v, pl->slot_dZ + v, mask, pl->slot_H + v, nd.token);
         }
         lv.off_dproj = (int)b.size();
         for (int v : bins) {

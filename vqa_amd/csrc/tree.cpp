@@ -42,6 +42,17 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
             p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
             if ((rc = vqa_conv_tiles(&p, 1, stream))) return rc;
         }
+        if (pl->C == 128 && !(c->flags & VQA_TREE_UNFUSED)) {   // both convolutions of the body in one kernel
+            vqa_resblock_params p = {};
+            p.arena = c->arena;
+            p.w_first = c->w_conv1; p.w_second = c->w_conv2;
+            p.bias_first = c->b_conv1; p.bias_second = c->b_conv2;
+            p.tiles = tiles_at(c, lv.off_fused_fwd); p.num_tiles = lv.count;
+            p.slot_stride = (int64_t)VQA_HW * 128; p.w_group_stride = w33;
+            p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
+            if ((rc = vqa_resblock_tiles(&p, stream))) return rc;
+            continue;
+        }
         {                      // H = relu(conv1(in) + b1)     Layers.py:33 / Module_Model.py:47
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->w_conv1; p.bias = c->b_conv1; p.w_group_stride = w33;
@@ -73,6 +84,14 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     int rc;
     for (int L = pl->num_levels - 1; L >= 0; L--) {
         const PlanLevel& lv = pl->levels[L];
+        if (pl->C == 128 && !(c->flags & VQA_TREE_UNFUSED)) {
+            vqa_resblock_params p = {};
+            p.arena = c->arena;
+            p.w_first = c->wd_conv2; p.w_second = c->wd_conv1;
+            p.tiles = tiles_at(c, lv.off_fused_bwd); p.num_tiles = lv.count;
+            p.slot_stride = slot; p.w_group_stride = w33;
+            if ((rc = vqa_resblock_tiles(&p, stream))) return rc;
+        } else {
         {   // dH = dgrad_conv2(dZ) * (H > 0)
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->wd_conv2; p.w_group_stride = w33;
@@ -84,6 +103,7 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
             p.w = c->wd_conv1; p.w_group_stride = w33;
             p.tiles = tiles_at(c, lv.off_dgrad1); p.num_tiles = lv.count;
             if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+        }
         }
         if (lv.bcount > 0) {   // [dx; dy] = dP * Wproj, each masked by its own child's output
             vqa_conv_params p = base_conv(pl, c);

@@ -199,7 +199,10 @@ class ModuleNet(nn.Module):
         self._packed_stale = False
         self._packed = {}
         self.used_fns = None
-        self.wgrad_chunk = 16
+        self.wgrad_chunk = 32
+        # module width 128: both convolutions of a residual body run in one kernel; False selects
+        # the two-launch path (bit-identical results)
+        self.fuse_residual_body = True
         self.grad_ready_hook = None   # set by the data-parallel wrapper: called as (name, grad tensor)
         self.backward_done_hook = None
         self.last_token_counts = None
@@ -321,6 +324,7 @@ class ModuleNet(nn.Module):
             for k in ('g_conv1', 'g_conv2', 'g_proj', 'gb_conv1', 'gb_conv2', 'gb_proj'):
                 setattr(ctx, k, grads[k].data_ptr())
         ctx.C, ctx.V = self._dims['c'], len(self._tokens)
+        ctx.flags = 0 if self.fuse_residual_body else _lib.TREE_UNFUSED
         return ctx
 
     def _run_forward(self, x, plan, need_grad):

@@ -47,6 +47,22 @@ def conv_tiles(src, dst, w_packed, tiles, num_tiles, *, taps, k_chunks, n_out, s
     _lib.check(_lib.load().vqa_conv_tiles(C.byref(p), taps, _stream()))
 
 
+def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=None, bias_second=None,
+                   relu=False, tiles_offset=0):
+    """Both 3x3 convolutions of a 128-wide residual body, one workgroup per tile
+    (vqa_resblock_tiles); `arena` is bf16 [slots][196][128]."""
+    _need_cuda(arena, w_first, w_second, tiles)
+    p = _lib.ResblockParams()
+    p.arena, p.w_first, p.w_second = arena.data_ptr(), w_first.data_ptr(), w_second.data_ptr()
+    p.bias_first = bias_first.data_ptr() if bias_first is not None else 0
+    p.bias_second = bias_second.data_ptr() if bias_second is not None else 0
+    p.tiles = tiles.data_ptr() + 4 * tiles_offset
+    p.slot_stride, p.w_group_stride = 196 * 128, 9 * 128 * 128
+    p.flags = (_lib.CONV_BIAS if bias_first is not None else 0) | (_lib.CONV_RELU if relu else 0)
+    p.num_tiles = num_tiles
+    _lib.check(_lib.load().vqa_resblock_tiles(C.byref(p), _stream()))
+
+
 def pack_conv_weight(w, groups, n_out, k_in, taps, g_stride, n_stride, k_stride, flip=False, out=None):
     """fp32 weights -> bf16 slabs [group][chunk][tap][half][n][64] (swizzled LDS image)."""
     _need_cuda(w)
