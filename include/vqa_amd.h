@@ -260,7 +260,8 @@ int vqa_slot_sum_mask(void* arena, const int32_t* offsets, const int32_t* src_sl
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing for the benchmark (no counterpart in the reference).  While enabled, every
  * launch of the MFMA kernels is bracketed by HIP events on its stream.  vqa_prof_collect waits for
- * them and writes, per kind k (0 conv3x3, 1 conv1x1, 2 wgrad3x3, 3 wgrad1x1, 4 gemm):
+ * them and writes, per kind k (0 conv3x3, 1 conv1x1, 2 wgrad3x3, 3 wgrad1x1, 4 gemm,
+ * 5 fused residual body; `kinds` >= 6):
  * out[4k] launches, out[4k+1] total ms, out[4k+2] algorithmic FLOPs, out[4k+3] algorithmic bytes.
  * ------------------------------------------------------------------------------------------ */
 int vqa_prof_enable(int32_t on);

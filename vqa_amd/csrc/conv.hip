@@ -407,7 +407,7 @@ extern "C" int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream) {
         attr_set = true;
     }
     // two 3x3 convolutions of 128 -> 128 channels per tile
-    VqaProfScope prof(VQA_K_CONV9, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles,
+    VqaProfScope prof(VQA_K_RESBLOCK, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles,
                       (double)p->num_tiles * VQA_HW * 2.0 * 128 * 3, (hipStream_t)stream);
     hipLaunchKernelGGL(resblock_tiles_kernel, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
     hipError_t e = hipGetLastError();

@@ -45,7 +45,7 @@ extern "C" int vqa_prof_enable(int32_t on) {
 // Waits for the recorded launches, then adds per kind: out[kind*4 + 0] launches, +1 total ms,
 // +2 algorithmic FLOPs, +3 algorithmic bytes.  Clears the records.
 extern "C" int vqa_prof_collect(double* out, int32_t kinds) {
-    if (!out || kinds < VQA_K_COUNT) { vqa_set_error("vqa_prof_collect: need room for 5 kinds"); return VQA_EINVAL; }
+    if (!out || kinds < VQA_K_COUNT) { vqa_set_error("vqa_prof_collect: need room for 6 kinds"); return VQA_EINVAL; }
     std::lock_guard<std::mutex> lk(g_mu);
     for (int i = 0; i < kinds * 4; i++) out[i] = 0.0;
     for (Rec& r : g_recs) {

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { VQA_K_CONV9 = 0, VQA_K_CONV1, VQA_K_WGRAD9, VQA_K_WGRAD1, VQA_K_GEMM, VQA_K_COUNT };
+enum { VQA_K_CONV9 = 0, VQA_K_CONV1, VQA_K_WGRAD9, VQA_K_WGRAD1, VQA_K_GEMM, VQA_K_RESBLOCK, VQA_K_COUNT };
 
 bool vqa_prof_on();
 // call right before / right after enqueueing a kernel of `kind`; flops / bytes are the launch's

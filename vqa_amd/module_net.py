@@ -53,7 +53,7 @@ class _Workspace:
     def __init__(self):
         self.bufs = {}
         self.busy = False
-        self.blob_event = None
+        self.host_event = None    # last transfer through this set's pinned host buffers
 
     def get(self, name, numel, dtype, device, zero=False):
         t = self.bufs.get(name)
@@ -63,6 +63,13 @@ class _Workspace:
         t = t[:numel]
         if zero:
             t.zero_()
+        return t
+
+    def get_capacity(self, name, numel, dtype, device):
+        """The whole grow-only buffer `name`, at least `numel` long (contents are lost on growth)."""
+        t = self.bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype or t.device != device:
+            t = self.bufs[name] = torch.empty(numel + numel // 8, dtype=dtype, device=device)
         return t
 
 
@@ -100,9 +107,9 @@ class _CallState(dict):
 
 class _ExecFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, x, plan, need_grad, *params):
+    def forward(ctx, net, x, program, need_grad, *params):
         ctx.net = net
-        st = net._run_forward(x, plan, need_grad)
+        st = net._run_forward(x, program, need_grad)
         # the output must not stay reachable from ctx: output -> grad_fn -> ctx -> state -> output is
         # a reference cycle that only the cyclic GC frees, and GBs of arena would pile up meanwhile
         logits = st.pop('logits')
@@ -195,6 +202,8 @@ class ModuleNet(nn.Module):
         self._binary = [V.get_num_inputs(t) == 2 for t in self._tokens]
         self._fc_idx = [i for i, m in enumerate(self.classifier) if isinstance(m, nn.Linear)]
         self._pool = _WorkspacePool()
+        self._side = None              # stream for host<->device traffic that must not queue behind compute
+        self._stem_tile_cache = {}
         self._packed_key = None
         self._packed_stale = False
         self._packed = {}
@@ -299,13 +308,9 @@ class ModuleNet(nn.Module):
             raise RuntimeError('vqa_amd.ModuleNet runs on an MI355X only: features must be a CUDA/HIP '
                                'tensor (no CPU fallback)')
         _lib.load()
-        plan = Plan(program.detach().cpu().numpy(), self.vocab, self._dims['c'], self.wgrad_chunk)
-        # Module_Model.py:227,231: a float tensor on the program's device
-        self.used_fns = torch.from_numpy(plan.used_fns()).to(program.device)
-        self.last_token_counts = plan.token_counts()
         params = [p for _, p in self._param_groups()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _ExecFn.apply(self, x, plan, need_grad, *params)
+        return _ExecFn.apply(self, x, program, need_grad, *params)
 
     def _conv(self, st, src, dst, w, tiles_sec, taps, k_chunks, n_out, src_geo, dst_geo, **kw):
         off, cnt = st['plan'].section(tiles_sec)
@@ -327,38 +332,112 @@ class ModuleNet(nn.Module):
         ctx.flags = 0 if self.fuse_residual_body else _lib.TREE_UNFUSED
         return ctx
 
-    def _run_forward(self, x, plan, need_grad):
+    def _stem_tiles(self, N, dev):
+        """Tile lists of the two stem convolutions (image i -> S0 slot N+i -> F slot i); they depend
+        on the batch size only, so the stem can be enqueued before the programs are parsed."""
+        key = (N, str(dev))
+        t = self._stem_tile_cache.get(key)
+        if t is None:
+            rows = np.full((2, N, 8), -1, dtype=np.int32)
+            i = np.arange(N, dtype=np.int32)
+            rows[0, :, 0], rows[0, :, 2] = i, N + i
+            rows[1, :, 0], rows[1, :, 2] = N + i, i
+            rows[:, :, 7] = 0
+            self._stem_tile_cache.clear()
+            t = self._stem_tile_cache[key] = torch.from_numpy(rows.reshape(-1)).to(dev)
+        return t
+
+    def _run_forward(self, x, program, need_grad):
+        """Order matters for the host/device overlap: the programs start their way to the host on a
+        side stream, the stem (which does not depend on them) is enqueued, and only then does the
+        host wait for the programs, parse them and upload the tile lists - under the stem kernels
+        instead of in front of an idle device."""
         d = self._dims
         dev = x.device
-        N, c, p_, cpad = plan.N, d['c'], d['p'], d['cin_pad']
+        N, c, p_, cpad = x.size(0), d['c'], d['p'], d['cin_pad']
         if x.dim() != 4 or tuple(x.shape[1:]) != (d['cin'], 14, 14):
             raise ValueError('features must be [N, %d, 14, 14]' % d['cin'])
+        T = program.size(1)
         pk = self._pack_weights(dev)
-        ws, info = self._pool.acquire(), plan.info
-        st = _CallState(plan=plan, N=N, pk=pk, ws=ws)
-        nb = info.blob_words
-        host = ws.bufs.get('blob_host')
-        if host is None or host.numel() < nb:
-            host = ws.bufs['blob_host'] = torch.empty(nb + nb // 4, dtype=torch.int32, pin_memory=True)
-            ws.blob_event = None
-        if ws.blob_event is not None:
-            ws.blob_event.synchronize()      # the previous upload from this pinned buffer has left the host
-        plan.blob_into(host)
-        st['blob'] = ws.get('blob', nb, torch.int32, dev)
-        st['blob'].copy_(host[:nb], non_blocking=True)
-        ws.blob_event = torch.cuda.Event()
-        ws.blob_event.record()
-        slots = info.slots_total if need_grad else info.slots_fwd
-        st['arena'] = arena = ws.get('arena', slots * HW * c, torch.bfloat16, dev)
-        xs = x.detach().to(torch.float32).contiguous()
-        st['x_nhwc'] = xn = ws.get('x_nhwc', N * HW * cpad, torch.bfloat16, dev)
-        ops.nchw_to_nhwc(xs, xn, N, d['cin'], cpad)
-        slot = (HW * c, c)
-        # stem: two conv3x3 + bias + ReLU over the whole batch (Module_Model.py:55-64,239)
-        self._conv(st, xn, arena, pk['w_stem0'], 'STEM0_TILES', 9, cpad // 128, c, (HW * cpad, cpad), slot,
-                   bias=pk['b_stem0'], relu=True)
-        self._conv(st, arena, arena, pk['w_stem1'], 'STEM1_TILES', 9, c // 128, c, slot, slot,
-                   bias=pk['b_stem1'], relu=True)
+        ws = self._pool.acquire()
+        st = _CallState(N=N, pk=pk, ws=ws)
+        try:
+            cur = torch.cuda.current_stream(dev)
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(dev)
+            side = self._side
+            if ws.host_event is not None:
+                ws.host_event.synchronize()      # earlier transfers through this set's pinned buffers are over
+            hp = ws.bufs.get('prog_host')
+            if hp is None or hp.numel() < N * T:
+                hp = ws.bufs['prog_host'] = torch.empty(N * T + N * T // 4, dtype=torch.int64, pin_memory=True)
+            hprog = hp[:N * T].view(N, T)
+            # the side stream starts behind everything already enqueued here: whatever produced the
+            # programs, and the previous call's kernels that still read this set's tile lists
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            side.wait_event(ready)
+            if program.is_cuda:
+                prog_dev = program.detach().to(torch.int64).contiguous()
+                with torch.cuda.stream(side):
+                    hprog.copy_(prog_dev, non_blocking=True)
+                    arrived = torch.cuda.Event()
+                    arrived.record(side)
+            else:
+                hprog.copy_(program.detach().to(torch.int64))
+                arrived = None
+
+            # stem: two conv3x3 + bias + ReLU over the whole batch (Module_Model.py:55-64,239)
+            slot = (HW * c, c)
+            stem_elems = 2 * N * HW * c
+            arena_full = ws.get_capacity('arena', stem_elems, torch.bfloat16, dev)
+            xs = x.detach().to(torch.float32).contiguous()
+            st['x_nhwc'] = xn = ws.get('x_nhwc', N * HW * cpad, torch.bfloat16, dev)
+            ops.nchw_to_nhwc(xs, xn, N, d['cin'], cpad)
+            stem_tiles = self._stem_tiles(N, dev)
+            geo = dict(taps=9, n_out=c, dst_slot_stride=slot[0], dst_pix_stride=slot[1], w_group_stride=0, relu=True)
+            ops.conv_tiles(xn, arena_full, pk['w_stem0'], stem_tiles, N, k_chunks=cpad // 128,
+                           src_slot_stride=HW * cpad, src_pix_stride=cpad, bias=pk['b_stem0'], **geo)
+            ops.conv_tiles(arena_full, arena_full, pk['w_stem1'], stem_tiles, N, k_chunks=c // 128,
+                           src_slot_stride=slot[0], src_pix_stride=slot[1], bias=pk['b_stem1'],
+                           tiles_offset=8 * N, **geo)
+
+            # programs -> plan -> tile lists on the device
+            if arrived is not None:
+                arrived.synchronize()
+            plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk)
+            st['plan'] = plan
+            info = plan.info
+            self.last_token_counts = plan.token_counts()
+            nb = info.blob_words
+            host = ws.bufs.get('blob_host')
+            if host is None or host.numel() < nb:
+                host = ws.bufs['blob_host'] = torch.empty(nb + nb // 4, dtype=torch.int32, pin_memory=True)
+            plan.blob_into(host)
+            hused = hp[:(N * T + 1) // 2].view(torch.float32)[:N * T].view(N, T)   # programs are parsed: reuse
+            plan.used_fns_into(hused)
+            st['blob'] = ws.get('blob', nb, torch.int32, dev)
+            # Module_Model.py:227,231: a float tensor on the program's device
+            used = torch.empty(N, T, dtype=torch.float32, device=program.device)
+            with torch.cuda.stream(side):
+                st['blob'].copy_(host[:nb], non_blocking=True)
+                if used.is_cuda:
+                    used.copy_(hused, non_blocking=True)
+                    used.record_stream(side)
+                else:
+                    used.copy_(hused)
+                ws.host_event = torch.cuda.Event()
+                ws.host_event.record(side)
+            cur.wait_event(ws.host_event)
+            self.used_fns = used
+            slots = info.slots_total if need_grad else info.slots_fwd
+            arena_big = ws.get_capacity('arena', slots * HW * c, torch.bfloat16, dev)
+            if arena_big.data_ptr() != arena_full.data_ptr():     # grew: carry the stem output over
+                arena_big[:stem_elems].copy_(arena_full[:stem_elems])
+            st['arena'] = arena = arena_big[:slots * HW * c]
+        except BaseException:
+            st.release()
+            raise
         # module trees, level by level
         tctx = self._tree_ctx(st, pk)
         _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))

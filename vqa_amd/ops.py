@@ -150,7 +150,7 @@ def slot_sum_mask(arena, blob, off_offsets, off_src, off_dst, off_mask, n_dst, s
                                              C.c_void_p(b + 4 * off_mask), n_dst, slot_elems, _stream()))
 
 
-KERNEL_KINDS = ('conv3x3', 'conv1x1', 'wgrad3x3', 'wgrad1x1', 'gemm')
+KERNEL_KINDS = ('conv3x3', 'conv1x1', 'wgrad3x3', 'wgrad1x1', 'gemm', 'resblock')
 
 
 def prof_enable(on):

@@ -48,6 +48,11 @@ class Plan:
         _lib.check(self._lib.vqa_plan_used_fns(self._h, out.ctypes.data_as(_lib.f32p)))
         return out
 
+    def used_fns_into(self, host_tensor):
+        """Write used_fns into a caller-provided float32 host tensor (e.g. pinned memory)."""
+        assert host_tensor.numel() >= self.N * self.T and host_tensor.dtype.is_floating_point
+        _lib.check(self._lib.vqa_plan_used_fns(self._h, C.cast(host_tensor.data_ptr(), _lib.f32p)))
+
     def nodes(self):
         """int32 [num_nodes, 6]: sample, token, column, child0, child1, level."""
         out = np.empty((self.info.num_nodes, 6), dtype=np.int32)
