@@ -258,13 +258,14 @@ int vqa_slot_sum_mask(void* arena, const int32_t* offsets, const int32_t* src_sl
                       int64_t slot_elems, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Per-kernel timing for the benchmark (no counterpart in the reference).  While enabled, every
- * launch of the MFMA kernels is bracketed by HIP events on its stream.  vqa_prof_collect waits for
+ * Per-kernel timing for the benchmark (no counterpart in the reference).  Every launch of an MFMA
+ * kernel whose kind is enabled is bracketed by HIP events on its stream (two event records per
+ * launch cost host time: enable only the kinds wanted).  vqa_prof_collect waits for
  * them and writes, per kind k (0 conv3x3, 1 conv1x1, 2 wgrad3x3, 3 wgrad1x1, 4 gemm,
  * 5 fused residual body; `kinds` >= 6):
  * out[4k] launches, out[4k+1] total ms, out[4k+2] algorithmic FLOPs, out[4k+3] algorithmic bytes.
  * ------------------------------------------------------------------------------------------ */
-int vqa_prof_enable(int32_t on);
+int vqa_prof_enable(int32_t kind_mask);   /* bit k set: time launches of kind k; 0: off */
 int vqa_prof_collect(double* out, int32_t kinds);
 
 /* ------------------------------------------------------------------------------------------

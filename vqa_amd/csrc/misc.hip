@@ -13,23 +13,46 @@
     } while (0)
 
 // x [n][Cin][196] (fp32) -> out [n][196][Cpad] (bf16); channels Cin..Cpad-1 are written as zero.
-// Block = one sample x 64 channels, staged through LDS so both sides are coalesced.
+// Block = one sample x 64 channels.  Reads are 16 bytes per lane with every load of a thread in
+// flight at once; the tile sits in LDS as bf16 [channel][198] (odd dword stride: the column reads
+// of the second phase are conflict-free, 25 KB per block so six blocks share a CU); writes are
+// 16 bytes per lane, 128 contiguous bytes per pixel.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x,
                                                            bf16_t* __restrict__ out, int Cin, int Cpad) {
-    __shared__ float tile[64 * 197];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 198];
     const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
-    const float* xs = x + ((int64_t)n * Cin + c0) * VQA_HW;
-    for (int idx = tid; idx < 64 * VQA_HW; idx += 256) {
-        const int c = idx / VQA_HW, pix = idx - c * VQA_HW;
-        tile[c * 197 + pix] = (c0 + c < Cin) ? xs[idx] : 0.f;
+    const float4* xs = (const float4*)(x + ((int64_t)n * Cin + c0) * VQA_HW);
+    const int cvalid = min(64, Cin - c0);
+    float4 v[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int f = tid + 256 * i;            // float4 index: channel f / 49, pixels 4 * (f % 49)..+3
+        const int c = f / 49;
+        v[i] = (f < 64 * 49 && c < cvalid) ? xs[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int f = tid + 256 * i;
+        if (f < 64 * 49) {
+            const int c = f / 49, pix = (f - c * 49) * 4;
+            uint32_t* t = (uint32_t*)(tile + c * 198 + pix);
+            t[0] = (uint32_t)f2bf(v[i].x) | ((uint32_t)f2bf(v[i].y) << 16);
+            t[1] = (uint32_t)f2bf(v[i].z) | ((uint32_t)f2bf(v[i].w) << 16);
+        }
     }
     __syncthreads();
     bf16_t* os = out + (int64_t)n * VQA_HW * Cpad + c0;
-    for (int idx = tid; idx < VQA_HW * 16; idx += 256) {
-        const int pix = idx >> 4, cg = (idx & 15) * 4;
-        u16x4 o = {f2bf(tile[(cg + 0) * 197 + pix]), f2bf(tile[(cg + 1) * 197 + pix]),
-                   f2bf(tile[(cg + 2) * 197 + pix]), f2bf(tile[(cg + 3) * 197 + pix])};
-        *(u16x4*)(os + (int64_t)pix * Cpad + cg) = o;
+    for (int idx = tid; idx < VQA_HW * 8; idx += 256) {
+        // lanes run along the pixels (bank-conflict-free column reads); a pixel's eight 16-byte
+        // pieces are written by eight different waves' iterations, each a full 16 B
+        const int cg = (idx / VQA_HW) * 8, pix = idx - (idx / VQA_HW) * VQA_HW;
+        const bf16_t* t = tile + cg * 198 + pix;
+        uint4 o;
+        o.x = (uint32_t)t[0] | ((uint32_t)t[198] << 16);
+        o.y = (uint32_t)t[2 * 198] | ((uint32_t)t[3 * 198] << 16);
+        o.z = (uint32_t)t[4 * 198] | ((uint32_t)t[5 * 198] << 16);
+        o.w = (uint32_t)t[6 * 198] | ((uint32_t)t[7 * 198] << 16);
+        *(uint4*)(os + (int64_t)pix * Cpad + cg) = o;
     }
 }
 

@@ -9,7 +9,7 @@
 namespace {
 struct Rec { int kind; double flops, bytes; hipEvent_t a, b; };
 std::mutex g_mu;
-bool g_on = false;
+unsigned g_mask = 0;   // bit k: launches of kind k are timed
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 Rec g_open;
@@ -22,7 +22,7 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-bool vqa_prof_on() { return g_on; }
+bool vqa_prof_on(int kind) { return (g_mask >> kind) & 1u; }
 
 void vqa_prof_begin(int kind, double flops, double bytes, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -36,9 +36,9 @@ void vqa_prof_end(hipStream_t s) {
     g_recs.push_back(g_open);
 }
 
-extern "C" int vqa_prof_enable(int32_t on) {
+extern "C" int vqa_prof_enable(int32_t kind_mask) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_on = on != 0;
+    g_mask = (unsigned)kind_mask;
     return VQA_OK;
 }
 

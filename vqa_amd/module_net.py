@@ -530,14 +530,30 @@ class ModuleNet(nn.Module):
             name = 'classifier.%d' % self._fc_idx[li]
             # weight gradient: dW[fo][fi] = g^T (rows = samples) x input activations
             gw = torch.empty(fo, fi, **f32)
-            tmp = gw if li > 0 else ws.get('fc0_gw', fo * fi, torch.float32, dev)
-            ops.gemm(g, acts[li], tmp, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
-            if li == 0:
-                ops.fc_grad_from_nhwc(tmp, gw, fo, p_)
+            if li > 0:
+                ops.gemm(g, acts[li], gw, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
+                if self.grad_ready_hook is not None:
+                    self.grad_ready_hook(name + '.weight', gw)
+                    emitted.add(name + '.weight')
+            else:
+                # The weight gradient of the first linear layer (most of the network's parameters)
+                # feeds nothing else in this pass: it runs on the side stream, next to the small
+                # top-of-tree launches that follow and cannot fill the device on their own.  Under
+                # data parallelism its all-reduce is issued from there as well, first of all.
+                tmp = ws.get('fc0_gw', fo * fi, torch.float32, dev)
+                cur, side = torch.cuda.current_stream(dev), self._side
+                fork = torch.cuda.Event()
+                fork.record(cur)
+                with torch.cuda.stream(side):
+                    side.wait_event(fork)
+                    ops.gemm(g, acts[li], tmp, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
+                    ops.fc_grad_from_nhwc(tmp, gw, fo, p_)
+                    if self.grad_ready_hook is not None:
+                        self.grad_ready_hook(name + '.weight', gw)
+                        emitted.add(name + '.weight')
+                    side_done = torch.cuda.Event()
+                    side_done.record(side)
             grads[name + '.weight'] = gw
-            if self.grad_ready_hook is not None:     # the big one first: its all-reduce overlaps the rest
-                self.grad_ready_hook(name + '.weight', gw)
-                emitted.add(name + '.weight')
             # input gradient, masked by the ReLU that produced the input
             gin = ws.get('fc_gin%d' % li, np128 * fi, torch.bfloat16, dev)
             if np128 != N:
@@ -613,6 +629,7 @@ class ModuleNet(nn.Module):
                 if self.grad_ready_hook is not None and name not in emitted:
                     self.grad_ready_hook(name, gr)
             out.append(gr if p.requires_grad else None)
+        torch.cuda.current_stream(dev).wait_event(side_done)
         self._packed_stale = True
         if self.backward_done_hook is not None:
             self.backward_done_hook()

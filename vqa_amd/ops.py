@@ -153,8 +153,16 @@ def slot_sum_mask(arena, blob, off_offsets, off_src, off_dst, off_mask, n_dst, s
 KERNEL_KINDS = ('conv3x3', 'conv1x1', 'wgrad3x3', 'wgrad1x1', 'gemm', 'resblock')
 
 
-def prof_enable(on):
-    _lib.check(_lib.load().vqa_prof_enable(int(on)))
+def prof_enable(kinds):
+    """Time launches of the given kernel kinds with HIP events: True = all, False = none, or an
+    iterable of names from KERNEL_KINDS."""
+    if kinds is True:
+        mask = (1 << len(KERNEL_KINDS)) - 1
+    elif not kinds:
+        mask = 0
+    else:
+        mask = sum(1 << KERNEL_KINDS.index(k) for k in kinds)
+    _lib.check(_lib.load().vqa_prof_enable(mask))
 
 
 def prof_collect():
