@@ -57,10 +57,15 @@ typedef struct {
 
 /* programs: host int64 [N][T].  arity: int8 [V] (0 scene, 1 unary, 2 binary), indexed by token id
  * (Program_funcs.py:114-122).  null_id / start_id: ids of <NULL> and <START> (Functions.py:44-45).
- * scene_id: id of 'scene'.  C: module width.  wgrad_chunk: nodes per weight-gradient work item. */
+ * scene_id: id of 'scene'.  C: module width.  wgrad_chunk: nodes per weight-gradient work item.
+ * flags: the blob holds, per tree level, one tile list per convolution pass (for vqa_conv_tiles) and
+ * the fused per-node lists (for vqa_resblock_tiles); a caller that will only run one of the two
+ * paths can leave the other's lists out, which halves the blob. */
+#define VQA_PLAN_SKIP_SEPARATE 1
+#define VQA_PLAN_SKIP_FUSED 2
 int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T, const int8_t* arity,
                        int32_t V, int32_t null_id, int32_t start_id, int32_t scene_id, int32_t C,
-                       int32_t wgrad_chunk, vqa_plan** out);
+                       int32_t wgrad_chunk, int32_t flags, vqa_plan** out);
 void vqa_plan_free(vqa_plan* plan);
 int vqa_plan_get_info(const vqa_plan* plan, vqa_plan_info* out);
 /* used_fns as ModuleNet.used_fns (Module_Model.py:227,231): float [N][T] of 0/1 */
@@ -141,24 +146,42 @@ typedef struct {
 
 int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps /* 9 or 1 */, void* stream);
 
-/* Fused residual body for module width 128: both 3x3 convolutions of one map in one workgroup
- * (Layers.py:33-36 / Module_Model.py:47-50 forward; their input gradients backward).  Tile fields:
- * src0 = input map, dst1 = intermediate map (conv1 output H, or dH), mask1 = mask of the
- * intermediate (backward: H) or -1, dst0 = final map, res = residual of the final map or -1,
- * mask0 = mask of the final map or -1.  All maps are slots of one arena, 256-byte pixels.
- *   intermediate = [relu](first(src) + bias_first) * (mask1 > 0)
- *   final        = [relu](second(intermediate) + bias_second + res) * (mask0 > 0) */
+/* Fused module body for module width 128: every convolution of one tree node in one workgroup
+ * (Layers.py:33-36 / Module_Model.py:38-40,47-50 forward; their input gradients backward).  All
+ * maps are slots of one arena, 256-byte pixels.
+ *   [pre, if src1 >= 0:  slot res = [relu](pre([src0; src1]) + bias_pre), and the input is that map;
+ *    otherwise the input is src0]
+ *   slot dst1 = [relu](first(input) + bias_first) * (mask1 > 0)
+ *   slot dst0 = [relu](second(dst1 map) + bias_second + res) * (mask0 > 0)
+ *   [post, if post_dst0 >= 0:  (post_dst0, post_dst1) = post(dst0 map) * (post_mask0 > 0, post_mask1 > 0)]
+ * Forward of a ConcatBlock uses pre (the 1x1 projection of the concatenated children); its backward
+ * uses post (the transposed projection, one half of its 256 outputs per child). */
+typedef struct {
+    int32_t src0, src1;
+    int32_t dst0, dst1;
+    int32_t res;                /* -1: none */
+    int32_t mask0, mask1;       /* -1: none */
+    int32_t wgroup;             /* weight group (token id) */
+    int32_t post_dst0, post_dst1, post_mask0, post_mask1;
+} vqa_resblock_tile;
+
 typedef struct {
     void* arena;
-    const void* w_first;        /* packed weights of the first convolution, one group per token */
+    const void* w_first;        /* packed 3x3 weights of the first convolution, one group per token */
     const void* w_second;
+    const void* w_pre;          /* packed 1x1 weights, K = 256 (two sources), 128 outputs; or null */
+    const void* w_post;         /* packed 1x1 weights, K = 128, 256 outputs; or null */
     const float* bias_first;    /* fp32 [groups][128] or null */
     const float* bias_second;
-    const vqa_conv_tile* tiles; /* device */
+    const float* bias_pre;
+    const vqa_resblock_tile* tiles; /* device */
     int64_t slot_stride;        /* elements between slots (196 * 128) */
-    int64_t w_group_stride;     /* elements between weight groups (9 * 128 * 128) */
-    int32_t flags;              /* VQA_CONV_BIAS | VQA_CONV_RELU, applied to both convolutions */
+    int64_t w_group_stride;     /* elements between 3x3 weight groups (9 * 128 * 128) */
+    int64_t w_pre_group_stride; /* elements between 1x1 weight groups (2 * 128 * 128), pre and post */
+    int32_t flags;              /* VQA_CONV_BIAS | VQA_CONV_RELU, applied to every convolution but post */
     int32_t num_tiles;
+    int32_t num_pre, num_post;  /* how many tiles have a pre / post part (work accounting and
+                                   argument checks; the kernel decides per tile) */
 } vqa_resblock_params;
 
 int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);

@@ -151,7 +151,7 @@ def test_resblock_fused_matches_two_launches_and_torch(backward):
         p2 = ops.pack_conv_weight(w2.to(dev()), G, C, C, 9, C * C * 9, C * 9, 9)
         bias1, bias2 = b1.to(dev()), b2.to(dev())
         m1 = m0 = lambda i: -1
-    fused = tiles_tensor([[i, -1, 4 * S + i, 3 * S + i, i, m0(i), m1(i), groups[i]] for i in range(S)])
+    fused = tiles_tensor([[i, -1, 4 * S + i, 3 * S + i, i, m0(i), m1(i), groups[i], -1, -1, -1, -1] for i in range(S)])
     ops.resblock_tiles(arena, p1, p2, fused, S, bias_first=bias1, bias_second=bias2, relu=not backward)
     first = tiles_tensor([[i, -1, 5 * S + i, -1, -1, m1(i), -1, groups[i]] for i in range(S)])
     second = tiles_tensor([[5 * S + i, -1, 6 * S + i, -1, i, m0(i), -1, groups[i]] for i in range(S)])
@@ -177,6 +177,65 @@ def test_resblock_fused_matches_two_launches_and_torch(backward):
         out_ref.append(out)
     close(from_slots(arena[3 * S:4 * S], C), torch.stack(mid_ref))
     close(from_slots(arena[4 * S:5 * S], C), torch.stack(out_ref), tol=2e-2)
+
+
+def test_resblock_fused_with_projection_pre_and_post():
+    """Binary nodes: the fused kernel also runs the 1x1 projection of the two children in front
+    (forward) and the transposed projection behind (backward); compared bit for bit with the
+    separate launches."""
+    from vqa_amd import ops
+    C, G, S = 128, 2, 5
+    x0, x1 = bf(F.relu(rnd((S, C, 14, 14), 51))), bf(F.relu(rnd((S, C, 14, 14), 52)))
+    w1 = bf(rnd((G, C, C, 3, 3), 53, 0.04))
+    w2 = bf(rnd((G, C, C, 3, 3), 54, 0.04))
+    wp = bf(rnd((G, C, 2 * C, 1, 1), 55, 0.06))
+    b1, b2, bp = rnd((G, C), 56, 0.1), rnd((G, C), 57, 0.1), rnd((G, C), 58, 0.1)
+    groups = [0, 1, 1, 0, 1]
+    zeros = lambda k: torch.zeros(k * S, HW, C, dtype=torch.bfloat16, device=dev())
+    d = dev()
+    geo = dict(k_chunks=1, n_out=C, src_slot_stride=HW * C, dst_slot_stride=HW * C, src_pix_stride=C,
+               dst_pix_stride=C)
+    # ---- forward.  slots: x0 | x1 | P H Y (fused) | P H Y (separate)
+    arena = torch.cat([to_slots(x0), to_slots(x1), zeros(6)])
+    p1 = ops.pack_conv_weight(w1.to(d), G, C, C, 9, C * C * 9, C * 9, 9)
+    p2 = ops.pack_conv_weight(w2.to(d), G, C, C, 9, C * C * 9, C * 9, 9)
+    pp = ops.pack_conv_weight(wp.to(d), G, C, 2 * C, 1, 2 * C * C, 2 * C, 1)
+    fused = tiles_tensor([[i, S + i, 4 * S + i, 3 * S + i, 2 * S + i, -1, -1, groups[i], -1, -1, -1, -1] for i in range(S)])
+    ops.resblock_tiles(arena, p1, p2, fused, S, bias_first=b1.to(d), bias_second=b2.to(d), relu=True,
+                       w_pre=pp, bias_pre=bp.to(d), num_pre=S)
+    t_proj = tiles_tensor([[i, S + i, 5 * S + i, -1, -1, -1, -1, groups[i]] for i in range(S)])
+    t_c1 = tiles_tensor([[5 * S + i, -1, 6 * S + i, -1, -1, -1, -1, groups[i]] for i in range(S)])
+    t_c2 = tiles_tensor([[6 * S + i, -1, 7 * S + i, -1, 5 * S + i, -1, -1, groups[i]] for i in range(S)])
+    ops.conv_tiles(arena, arena, pp, t_proj, S, taps=1, w_group_stride=2 * C * C, bias=bp.to(d), pair_chunks=1,
+                   relu=True, **dict(geo, k_chunks=2))
+    ops.conv_tiles(arena, arena, p1, t_c1, S, taps=9, w_group_stride=9 * C * C, bias=b1.to(d), relu=True, **geo)
+    ops.conv_tiles(arena, arena, p2, t_c2, S, taps=9, w_group_stride=9 * C * C, bias=b2.to(d), res=arena, relu=True, **geo)
+    torch.cuda.synchronize()
+    assert torch.equal(arena[2 * S:5 * S], arena[5 * S:8 * S])
+    P = from_slots(arena[2 * S:3 * S], C)
+    ref_p = torch.stack([F.relu(F.conv2d(torch.cat([x0[i:i + 1], x1[i:i + 1]], 1), wp[groups[i]], bp[groups[i]]))[0] for i in range(S)])
+    close(P, ref_p)
+    assert from_slots(arena[4 * S:5 * S], C).abs().max() > 0
+    # ---- backward.  slots: dZ | H | P | x0 | x1 | dH dP dx0 dx1 (fused) | dH dP dx0 dx1 (separate)
+    dz = bf(rnd((S, C, 14, 14), 59))
+    hm = bf(F.relu(rnd((S, C, 14, 14), 60)))
+    arena = torch.cat([to_slots(dz), to_slots(hm), to_slots(ref_p), to_slots(x0), to_slots(x1), zeros(8)])
+    d1 = ops.pack_conv_weight(w1.to(d), G, C, C, 9, C * C * 9, 9, C * 9, flip=True)
+    d2 = ops.pack_conv_weight(w2.to(d), G, C, C, 9, C * C * 9, 9, C * 9, flip=True)
+    dp = ops.pack_conv_weight(wp.to(d), G, 2 * C, C, 1, 2 * C * C, 1, 2 * C)
+    fused = tiles_tensor([[i, -1, 6 * S + i, 5 * S + i, i, 2 * S + i, S + i, groups[i],
+                           7 * S + i, 8 * S + i, 3 * S + i, 4 * S + i] for i in range(S)])
+    ops.resblock_tiles(arena, d2, d1, fused, S, w_post=dp, num_post=S)
+    t_g2 = tiles_tensor([[i, -1, 9 * S + i, -1, -1, S + i, -1, groups[i]] for i in range(S)])
+    t_g1 = tiles_tensor([[9 * S + i, -1, 10 * S + i, -1, i, 2 * S + i, -1, groups[i]] for i in range(S)])
+    t_dp = tiles_tensor([[10 * S + i, -1, 11 * S + i, 12 * S + i, -1, 3 * S + i, 4 * S + i, groups[i]] for i in range(S)])
+    ops.conv_tiles(arena, arena, d2, t_g2, S, taps=9, w_group_stride=9 * C * C, mask=arena, **geo)
+    ops.conv_tiles(arena, arena, d1, t_g1, S, taps=9, w_group_stride=9 * C * C, res=arena, mask=arena, **geo)
+    ops.conv_tiles(arena, arena, dp, t_dp, S, taps=1, w_group_stride=2 * C * C, mask=arena, pair_out=1,
+                   **dict(geo, n_out=2 * C))
+    torch.cuda.synchronize()
+    assert torch.equal(arena[5 * S:9 * S], arena[9 * S:13 * S])
+    assert from_slots(arena[7 * S:9 * S], C).abs().max() > 0
 
 
 def test_conv1x1_dgrad_pair_out():

@@ -53,9 +53,10 @@ class TreeCtx(C.Structure):
 
 
 class ResblockParams(C.Structure):
-    _fields_ = [('arena', vp), ('w_first', vp), ('w_second', vp), ('bias_first', vp),
-                ('bias_second', vp), ('tiles', vp), ('slot_stride', i64), ('w_group_stride', i64),
-                ('flags', i32), ('num_tiles', i32)]
+    _fields_ = [('arena', vp), ('w_first', vp), ('w_second', vp), ('w_pre', vp), ('w_post', vp),
+                ('bias_first', vp), ('bias_second', vp), ('bias_pre', vp), ('tiles', vp),
+                ('slot_stride', i64), ('w_group_stride', i64), ('w_pre_group_stride', i64),
+                ('flags', i32), ('num_tiles', i32), ('num_pre', i32), ('num_post', i32)]
 
 
 SEC = {name: i for i, name in enumerate((
@@ -66,12 +67,13 @@ SEC = {name: i for i, name in enumerate((
 
 CONV_BIAS, CONV_RELU = 1, 2
 TREE_UNFUSED = 1
+PLAN_SKIP_SEPARATE, PLAN_SKIP_FUSED = 1, 2
 
 # name -> (restype, argtypes); every symbol include/vqa_amd.h declares
 SIGNATURES = {
     'vqa_version': (i32, []),
     'vqa_last_error': (C.c_char_p, []),
-    'vqa_schedule_build': (i32, [i64p, i32, i32, i8p, i32, i32, i32, i32, i32, i32,
+    'vqa_schedule_build': (i32, [i64p, i32, i32, i8p, i32, i32, i32, i32, i32, i32, i32,
                                  C.POINTER(vp)]),
     'vqa_plan_free': (None, [vp]),
     'vqa_plan_get_info': (i32, [vp, C.POINTER(PlanInfo)]),

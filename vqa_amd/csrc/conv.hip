@@ -252,31 +252,102 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused residual body (module width 128 only): two 3x3 convolutions of one map in one workgroup.
-//   forward :  H = relu(conv1(x) + b1);   Y  = relu(x + conv2(H) + b2)        (Layers.py:33-36)
-//   backward:  dH = dgrad2(dZ) * (H > 0); dX = (dgrad1(dH) + dZ) * (X > 0)
-// The intermediate map never makes a round trip: its accumulators are rounded to bf16 straight into
-// the halo image that the second convolution reads, and leave for HBM (it is needed again by the
-// backward pass / the weight gradients) as whole 256-byte rows from that image.  One launch per
-// tree level instead of two, one source load and one cold-start per node instead of two.
+// Fused module body (module width 128 only): every convolution of one tree node in one workgroup.
+//   forward :  [P = relu(proj([x0; x1]) + bp)]   H = relu(conv1(x) + b1);   Y = relu(x + conv2(H) + b2)
+//              (Layers.py:33-36, Module_Model.py:38-40,47-50; x = P for a binary node)
+//   backward:  dH = dgrad2(dZ) * (H > 0);   dX = (dgrad1(dH) + dZ) * (X > 0);
+//              [binary: (dx0, dx1) = dproj(dX) * (x0 > 0, x1 > 0)]
+// No intermediate map makes a round trip: accumulators are rounded to bf16 straight into the halo
+// image that the next convolution reads, and leave for HBM (they are needed again by the backward
+// pass / the weight gradients) as whole 256-byte rows from that image.  One launch per tree level,
+// one source load and one cold start per node.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_params p) {
-    extern __shared__ __attribute__((aligned(16))) char halo[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const vqa_conv_tile t = p.tiles[blockIdx.x];
-    const int64_t slot_b = p.slot_stride * 2;       // bytes per slot; pixel stride is 256 B (C = 128)
-    char* arena = (char*)p.arena;
 
-    const int64_t wstep = 8 * 1024;
-    const int64_t wgroup_off = (int64_t)t.wgroup * p.w_group_stride * 2 + (int64_t)(wave * 2) * 1024 + lane * 16;
-    const char* wbase = (const char*)p.w_first + wgroup_off;
-    bf16x8 wr[4][2];
+// accumulators (+ bias, ReLU) -> bf16 -> interior of the halo image; then a row-wise pass applies
+// an optional mask, rewrites the image and stores the map to `dst` in 16-byte pieces.  Clears acc.
+__device__ __forceinline__ void acc_to_image(char* halo, f32x4 (&acc)[MT][2], const float* bias, bool relu,
+                                             const char* mask, char* dst, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    uint4 mv[13];
+    if (mask) {
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int e = tid + 256 * i, pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
+            mv[i] = *(const uint4*)(mask + pix * 256 + pc * 16);
+        }
+    }
+    __syncthreads();        // every wave has finished reading the image
+    if (l15 < 14) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int ch = wave * 32 + n * 16 + lq * 4;
+            const float4 bv = bias ? *(const float4*)(bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                float o0 = acc[m][n][0] + bv.x, o1 = acc[m][n][1] + bv.y, o2 = acc[m][n][2] + bv.z, o3 = acc[m][n][3] + bv.w;
+                if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+                pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+                *(uint2*)(halo + ((m + 1) * 16 + l15 + 1) * HALO_STRIDE + ch * 2) = pk;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int e = tid + 256 * i, pix = e >> 4, pc = e & 15;
+        if (pix < VQA_HW) {
+            const int y = pix / 14, x = pix - y * 14;
+            uint4* cell = (uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16);
+            uint4 v = *cell;
+            if (mask) {
+                const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
+                uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (!((int16_t)(k[j] & 0xFFFF) > 0)) w4[j] &= 0xFFFF0000u;
+                    if (!((int16_t)(k[j] >> 16) > 0)) w4[j] &= 0x0000FFFFu;
+                }
+                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                *cell = v;
+            }
+            *(uint4*)(dst + pix * 256 + pc * 16) = v;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase, int64_t wstep) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         wr[i][0] = *(const bf16x8*)(wbase + i * wstep);
         wr[i][1] = *(const bf16x8*)(wbase + i * wstep + 1024);
     }
+}
+
+__global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_params p) {
+    extern __shared__ __attribute__((aligned(16))) char halo[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const vqa_resblock_tile t = p.tiles[blockIdx.x];
+    const int64_t slot_b = p.slot_stride * 2;       // bytes per slot; pixel stride is 256 B (C = 128)
+    char* arena = (char*)p.arena;
+    const bool relu = (p.flags & VQA_CONV_RELU) != 0, has_bias = (p.flags & VQA_CONV_BIAS) != 0;
+
+    const int64_t wstep = 8 * 1024;                 // 128 output channels: 8 fragments of 1 KiB per K-step
+    const int64_t wlane = (int64_t)(wave * 2) * 1024 + lane * 16;
+    const int64_t w33 = (int64_t)t.wgroup * p.w_group_stride * 2 + wlane;
+    const bool pre = t.src1 >= 0;
+    const char* wbase = pre ? (const char*)p.w_pre + (int64_t)t.wgroup * p.w_pre_group_stride * 2 + wlane
+                            : (const char*)p.w_first + w33;
+    bf16x8 wr[4][2];
+    load_wring(wr, wbase, wstep);
     halo_zero_border(halo, tid);
     f32x4 acc[MT][2];
 #pragma unroll
@@ -291,81 +362,57 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     halo_stage(halo, arena + (int64_t)t.src0 * slot_b, 256, tid, false);
     __syncthreads();
     int s = 0;
+    if (pre) {   // binary node: x = relu(proj([src0; src1]) + bias_pre), kept in slot `res`
+        conv_kloop<1>(halo, xaddr, wbase, wstep, 8, s, wr, acc, false);
+        __syncthreads();
+        halo_stage(halo, arena + (int64_t)t.src1 * slot_b, 256, tid, false);
+        __syncthreads();
+        conv_kloop<1>(halo, xaddr, wbase, wstep, 8, s, wr, acc, false);
+        wbase = (const char*)p.w_first + w33;
+        load_wring(wr, wbase, wstep);
+        acc_to_image(halo, acc, has_bias ? p.bias_pre + (int64_t)t.wgroup * 128 : nullptr, relu, nullptr,
+                     arena + (int64_t)t.res * slot_b, tid);
+        s = 0;
+    }
     conv_kloop<9>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
 
-    // ---- first epilogue: accumulators -> bf16 -> the image the second convolution reads
-    wbase = (const char*)p.w_second + wgroup_off;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {           // second weight stream starts now, lands under the epilogue
-        wr[i][0] = *(const bf16x8*)(wbase + i * wstep);
-        wr[i][1] = *(const bf16x8*)(wbase + i * wstep + 1024);
-    }
-    const char* m1 = t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr;
-    char* d1 = arena + (int64_t)t.dst1 * slot_b;
-    uint4 mv[13];
-    if (m1) {
-#pragma unroll
-        for (int i = 0; i < 13; i++) {
-            const int e = tid + 256 * i, pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
-            mv[i] = *(const uint4*)(m1 + pix * 256 + pc * 16);
-        }
-    }
-    const bool relu1 = (p.flags & VQA_CONV_RELU) != 0;
-    const float* b1 = (p.flags & VQA_CONV_BIAS) ? p.bias_first + (int64_t)t.wgroup * 128 : nullptr;
-    __syncthreads();        // every wave has finished reading the source image
-    if (l15 < 14) {
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            const int ch = wave * 32 + n * 16 + lq * 4;
-            const float4 bv = b1 ? *(const float4*)(b1 + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int m = 0; m < MT; m++) {
-                float o0 = acc[m][n][0] + bv.x, o1 = acc[m][n][1] + bv.y, o2 = acc[m][n][2] + bv.z, o3 = acc[m][n][3] + bv.w;
-                if (relu1) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
-                uint2 pk;
-                pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-                pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
-                *(uint2*)(halo + ((m + 1) * 16 + l15 + 1) * HALO_STRIDE + ch * 2) = pk;
-            }
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    // row-wise pass over the image: apply the mask (backward), store the intermediate map coalesced
-#pragma unroll
-    for (int i = 0; i < 13; i++) {
-        const int e = tid + 256 * i, pix = e >> 4, pc = e & 15;
-        if (pix < VQA_HW) {
-            const int y = pix / 14, x = pix - y * 14;
-            uint4* cell = (uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16);
-            uint4 v = *cell;
-            if (m1) {
-                const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
-                uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (!((int16_t)(k[j] & 0xFFFF) > 0)) w4[j] &= 0xFFFF0000u;
-                    if (!((int16_t)(k[j] >> 16) > 0)) w4[j] &= 0x0000FFFFu;
-                }
-                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                *cell = v;
-            }
-            *(uint4*)(d1 + pix * 256 + pc * 16) = v;
-        }
-    }
-    __syncthreads();
-
-    // ---- second convolution from the image, then the staged epilogue
+    // intermediate map -> the image the second convolution reads; its weight stream starts now and
+    // lands under the epilogue
+    wbase = (const char*)p.w_second + w33;
+    load_wring(wr, wbase, wstep);
+    acc_to_image(halo, acc, has_bias ? p.bias_first + (int64_t)t.wgroup * 128 : nullptr, relu,
+                 t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
     s = 0;
     conv_kloop<9>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
-    const float* b2 = (p.flags & VQA_CONV_BIAS) ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr;
-    const char* rsrc = t.res >= 0 ? arena + (int64_t)t.res * slot_b : nullptr;
-    const char* msrc = t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr;
-    conv_epilogue(halo, acc, b2, relu1, rsrc, msrc, arena + (int64_t)t.dst0 * slot_b, 128, tid);
+
+    const bool post = t.post_dst0 >= 0;
+    char* d0 = arena + (int64_t)t.dst0 * slot_b;
+    conv_epilogue(halo, acc, has_bias ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr, relu,
+                  t.res >= 0 ? arena + (int64_t)t.res * slot_b : nullptr,
+                  t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, d0, 128, tid);
+    if (!post) return;
+
+    // binary node, backward: the map just stored (dP) goes through the transposed 1x1 projection,
+    // 256 outputs = one pass per child; the epilogue staging destroys the image, so it is staged
+    // again for the second pass (a 50 KB read that hits in L2)
+#pragma unroll 1
+    for (int child = 0; child < 2; child++) {
+        wbase = (const char*)p.w_post + (int64_t)t.wgroup * p.w_pre_group_stride * 2 + wlane + child * 8 * 1024;
+        load_wring(wr, wbase, 2 * wstep);
+        __syncthreads();     // the epilogue's stores are issued and its staging reads are done
+        halo_stage(halo, d0, 256, tid, false);
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        s = 0;
+        conv_kloop<1>(halo, xaddr, wbase, 2 * wstep, 4, s, wr, acc, false);
+        const int dslot = child ? t.post_dst1 : t.post_dst0, mslot = child ? t.post_mask1 : t.post_mask0;
+        conv_epilogue(halo, acc, nullptr, false, nullptr, mslot >= 0 ? arena + (int64_t)mslot * slot_b : nullptr,
+                      arena + (int64_t)dslot * slot_b, 128, tid);
+    }
 }
 
 extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stream) {
@@ -396,7 +443,9 @@ extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stre
 
 extern "C" int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream) {
     if (!p || !p->arena || !p->w_first || !p->w_second || !p->tiles || p->num_tiles < 0 ||
-        ((p->flags & VQA_CONV_BIAS) && (!p->bias_first || !p->bias_second))) {
+        ((p->flags & VQA_CONV_BIAS) && (!p->bias_first || !p->bias_second)) ||
+        (p->num_pre > 0 && (!p->w_pre || ((p->flags & VQA_CONV_BIAS) && !p->bias_pre))) ||
+        (p->num_post > 0 && !p->w_post)) {
         vqa_set_error("vqa_resblock_tiles: bad argument");
         return VQA_EINVAL;
     }
@@ -406,8 +455,9 @@ extern "C" int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream) {
         (void)hipFuncSetAttribute((const void*)resblock_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
         attr_set = true;
     }
-    // two 3x3 convolutions of 128 -> 128 channels per tile
-    VqaProfScope prof(VQA_K_RESBLOCK, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles,
+    // two 3x3 convolutions of 128 -> 128 channels per tile, plus the 1x1 projection of binary nodes
+    VqaProfScope prof(VQA_K_RESBLOCK, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles +
+                                          2.0 * VQA_HW * 256.0 * 128.0 * (p->num_pre + p->num_post),
                       (double)p->num_tiles * VQA_HW * 2.0 * 128 * 3, (hipStream_t)stream);
     hipLaunchKernelGGL(resblock_tiles_kernel, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
     hipError_t e = hipGetLastError();

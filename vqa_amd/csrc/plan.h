@@ -27,6 +27,7 @@ struct vqa_plan {
     int num_scene = 0, num_unary = 0, num_binary = 0, num_levels = 0, max_level_tiles = 0;
     int slot_F = 0, slot_S0 = 0, slot_Y = 0, slot_H = 0, slot_P = 0, slots_fwd = 0;
     int slot_dZ = 0, slot_dH = 0, slot_dP = 0, slot_dFp = 0, slot_dF = 0, slot_dS0 = 0, slots_total = 0;
+    bool has_separate = true, has_fused = true;   // which per-level tile lists the blob holds
     int sec_off[VQA_SEC_COUNT] = {0};
     int sec_cnt[VQA_SEC_COUNT] = {0};
 };

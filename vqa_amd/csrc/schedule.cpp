@@ -96,7 +96,7 @@ inline void push_tile(std::vector<int32_t>& b, int s0, int s1, int d0, int d1, i
 extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
                                   const int8_t* arity, int32_t V, int32_t null_id,
                                   int32_t start_id, int32_t scene_id, int32_t C,
-                                  int32_t wgrad_chunk, vqa_plan** out) {
+                                  int32_t wgrad_chunk, int32_t flags, vqa_plan** out) {
     if (!programs || !arity || !out || N <= 0 || T <= 0 || V <= 0 || scene_id < 0 ||
         scene_id >= V || C <= 0 || C % 128 != 0 || wgrad_chunk <= 0) {
         vqa_set_error("vqa_schedule_build: bad argument");
@@ -168,7 +168,7 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
     };
 
     std::vector<int32_t>& b = pl->blob;
-    b.reserve((size_t)NV * 72 + (size_t)N * 64 + (size_t)nb * 24 + 1024);
+    b.reserve((size_t)NV * 80 + (size_t)N * 64 + (size_t)nb * 24 + 1024);
     pl->levels.assign(pl->num_levels, {});
     int max_tiles = 0;
     for (int L = 0; L < pl->num_levels; L++) {
@@ -180,57 +180,76 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
         std::vector<int> bins;
         for (int v : nodes) if (pl->nodes[v].child1 >= 0) bins.push_back(v);
         lv.bcount = (int)bins.size();
-        lv.off_proj = (int)b.size();
-        for (int v : bins) {
-            const PlanNode& nd = pl->nodes[v];
-            push_tile(b, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
-                      pl->slot_P + pl->bin_index[v], -1, -1, -1, -1, nd.token);
+        if (!(flags & VQA_PLAN_SKIP_SEPARATE)) {   // one tile list per convolution pass
+            lv.off_proj = (int)b.size();
+            for (int v : bins) {
+                const PlanNode& nd = pl->nodes[v];
+                push_tile(b, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
+                          pl->slot_P + pl->bin_index[v], -1, -1, -1, -1, nd.token);
+            }
+            lv.off_conv1 = (int)b.size();
+            for (int v : nodes)
+                push_tile(b, in_slot(v), -1, pl->slot_H + v, -1, -1, -1, -1, pl->nodes[v].token);
+            lv.off_conv2 = (int)b.size();
+            for (int v : nodes)
+                push_tile(b, pl->slot_H + v, -1, pl->slot_Y + v, -1, in_slot(v), -1, -1,
+                          pl->nodes[v].token);
+            // backward: dH = dgrad_conv2(dZ) * (H > 0)
+            lv.off_dgrad2 = (int)b.size();
+            for (int v : nodes)
+                push_tile(b, pl->slot_dZ + v, -1, pl->slot_dH + v, -1, -1, pl->slot_H + v, -1,
+                          pl->nodes[v].token);
+            // d(input) = (dgrad_conv1(dH) + dZ) * (input > 0); a scene node's input is the shared
+            // stem map, so its gradient goes unmasked to a per-node slot and is summed later
+            lv.off_dgrad1 = (int)b.size();
+            for (int v : nodes) {
+                const PlanNode& nd = pl->nodes[v];
+                int dst, mask;
+                if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
+                else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
+                else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
+                push_tile(b, pl->slot_dH + v, -1, dst, -1, pl->slot_dZ + v, mask, -1, nd.token);
+            }
         }
-        lv.off_conv1 = (int)b.size();
-        for (int v : nodes)
-            push_tile(b, in_slot(v), -1, pl->slot_H + v, -1, -1, -1, -1, pl->nodes[v].token);
-        lv.off_conv2 = (int)b.size();
-        for (int v : nodes)
-            push_tile(b, pl->slot_H + v, -1, pl->slot_Y + v, -1, in_slot(v), -1, -1,
-                      pl->nodes[v].token);
-        // backward: dH = dgrad_conv2(dZ) * (H > 0)
-        lv.off_dgrad2 = (int)b.size();
-        for (int v : nodes)
-            push_tile(b, pl->slot_dZ + v, -1, pl->slot_dH + v, -1, -1, pl->slot_H + v, -1,
-                      pl->nodes[v].token);
-        // d(input) = (dgrad_conv1(dH) + dZ) * (input > 0); a scene node's input is the shared
-        // stem map, so its gradient goes unmasked to a per-node slot and is summed later
-        lv.off_dgrad1 = (int)b.size();
-        for (int v : nodes) {
-            const PlanNode& nd = pl->nodes[v];
-            int dst, mask;
-            if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
-            else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
-            else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
-            push_tile(b, pl->slot_dH + v, -1, dst, -1, pl->slot_dZ + v, mask, -1, nd.token);
+        if (!(flags & VQA_PLAN_SKIP_SEPARATE)) {
+            lv.off_dproj = (int)b.size();
+            for (int v : bins) {
+                const PlanNode& nd = pl->nodes[v];
+                push_tile(b, pl->slot_dP + pl->bin_index[v], -1, pl->slot_dZ + nd.child0,
+                          pl->slot_dZ + nd.child1, -1, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
+                          nd.token);
+            }
         }
-        // the same four passes as two fused tiles per node: forward (x -> H -> Y), backward (dZ -> dH -> dX)
-        lv.off_fused_fwd = (int)b.size();
-        for (int v : nodes)
-            push_tile(b, in_slot(v), -1, pl->slot_Y + v, pl->slot_H + v, in_slot(v), -1, -1, pl->nodes[v].token);
-        lv.off_fused_bwd = (int)b.size();
-        for (int v : nodes) {
-            const PlanNode& nd = pl->nodes[v];
-            int dst, mask;
-            if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
-            else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
-            else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
-            push_tile(b, pl->slot_dZ + v, -1, dst, pl->slot_dH + v, pl->slot_dZ + v, mask, pl->slot_H + v, nd.token);
-        }
-        lv.off_dproj = (int)b.size();
-        for (int v : bins) {
-            const PlanNode& nd = pl->nodes[v];
-            push_tile(b, pl->slot_dP + pl->bin_index[v], -1, pl->slot_dZ + nd.child0,
-                      pl->slot_dZ + nd.child1, -1, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
-                      nd.token);
+        if (!(flags & VQA_PLAN_SKIP_FUSED)) {
+            // the same passes as two fused tiles per node (vqa_resblock_tile, 12 words): forward
+            // ([children -> P] -> H -> Y) and backward (dZ -> dH -> dX [-> children's dZ])
+            lv.off_fused_fwd = (int)b.size();
+            for (int v : nodes) {
+                const PlanNode& nd = pl->nodes[v];
+                const int in = in_slot(v);
+                const bool bin = nd.child1 >= 0;
+                const int32_t w[12] = {bin ? pl->slot_Y + nd.child0 : in, bin ? pl->slot_Y + nd.child1 : -1,
+                                       pl->slot_Y + v, pl->slot_H + v, in, -1, -1, nd.token, -1, -1, -1, -1};
+                b.insert(b.end(), w, w + 12);
+            }
+            lv.off_fused_bwd = (int)b.size();
+            for (int v : nodes) {
+                const PlanNode& nd = pl->nodes[v];
+                int dst, mask;
+                if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
+                else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
+                else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
+                const bool bin = nd.child1 >= 0;
+                const int32_t w[12] = {pl->slot_dZ + v, -1, dst, pl->slot_dH + v, pl->slot_dZ + v, mask, pl->slot_H + v, nd.token,
+                                       bin ? pl->slot_dZ + nd.child0 : -1, bin ? pl->slot_dZ + nd.child1 : -1,
+                                       bin ? pl->slot_Y + nd.child0 : -1, bin ? pl->slot_Y + nd.child1 : -1};
+                b.insert(b.end(), w, w + 12);
+            }
         }
     }
     pl->max_level_tiles = max_tiles;
+    pl->has_separate = !(flags & VQA_PLAN_SKIP_SEPARATE);
+    pl->has_fused = !(flags & VQA_PLAN_SKIP_FUSED);
 
     // per-sample sections
     auto sec = [&](int id) { pl->sec_off[id] = (int)b.size(); };

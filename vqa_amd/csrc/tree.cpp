@@ -31,9 +31,26 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
     }
     const int cc = pl->C / 128;
     const int64_t w33 = (int64_t)9 * pl->C * pl->C, w11 = (int64_t)2 * pl->C * pl->C;
+    const bool fused = pl->C == 128 && !(c->flags & VQA_TREE_UNFUSED);
+    if (fused ? !pl->has_fused : !pl->has_separate) {
+        vqa_set_error("vqa_tree_forward: the plan was built without the tile lists of this path");
+        return VQA_EINVAL;
+    }
     for (int L = 0; L < pl->num_levels; L++) {
         const PlanLevel& lv = pl->levels[L];
         int rc;
+        if (fused) {   // the whole node in one kernel
+            vqa_resblock_params p = {};
+            p.arena = c->arena;
+            p.w_first = c->w_conv1; p.w_second = c->w_conv2; p.w_pre = c->w_proj;
+            p.bias_first = c->b_conv1; p.bias_second = c->b_conv2; p.bias_pre = c->b_proj;
+            p.tiles = (const vqa_resblock_tile*)(c->blob + lv.off_fused_fwd); p.num_tiles = lv.count;
+            p.num_pre = lv.bcount;
+            p.slot_stride = (int64_t)VQA_HW * 128; p.w_group_stride = w33; p.w_pre_group_stride = w11;
+            p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
+            if ((rc = vqa_resblock_tiles(&p, stream))) return rc;
+            continue;
+        }
         if (lv.bcount > 0) {   // P = relu(proj([x; y]) + b)   Module_Model.py:38-39
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->w_proj; p.bias = c->b_proj; p.w_group_stride = w11;
@@ -41,17 +58,6 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
             p.k_chunks = 2 * cc; p.pair_chunks = cc;
             p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
             if ((rc = vqa_conv_tiles(&p, 1, stream))) return rc;
-        }
-        if (pl->C == 128 && !(c->flags & VQA_TREE_UNFUSED)) {   // both convolutions of the body in one kernel
-            vqa_resblock_params p = {};
-            p.arena = c->arena;
-            p.w_first = c->w_conv1; p.w_second = c->w_conv2;
-            p.bias_first = c->b_conv1; p.bias_second = c->b_conv2;
-            p.tiles = tiles_at(c, lv.off_fused_fwd); p.num_tiles = lv.count;
-            p.slot_stride = (int64_t)VQA_HW * 128; p.w_group_stride = w33;
-            p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
-            if ((rc = vqa_resblock_tiles(&p, stream))) return rc;
-            continue;
         }
         {                      // H = relu(conv1(in) + b1)     Layers.py:33 / Module_Model.py:47
             vqa_conv_params p = base_conv(pl, c);
@@ -81,17 +87,24 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     const int cc = pl->C / 128;
     const int64_t w33 = (int64_t)9 * pl->C * pl->C, w11 = (int64_t)2 * pl->C * pl->C;
     const int64_t slot = (int64_t)VQA_HW * pl->C;
+    const bool fused = pl->C == 128 && !(c->flags & VQA_TREE_UNFUSED);
+    if (fused ? !pl->has_fused : !pl->has_separate) {
+        vqa_set_error("vqa_tree_backward: the plan was built without the tile lists of this path");
+        return VQA_EINVAL;
+    }
     int rc;
     for (int L = pl->num_levels - 1; L >= 0; L--) {
         const PlanLevel& lv = pl->levels[L];
-        if (pl->C == 128 && !(c->flags & VQA_TREE_UNFUSED)) {
+        if (fused) {
             vqa_resblock_params p = {};
             p.arena = c->arena;
-            p.w_first = c->wd_conv2; p.w_second = c->wd_conv1;
-            p.tiles = tiles_at(c, lv.off_fused_bwd); p.num_tiles = lv.count;
-            p.slot_stride = slot; p.w_group_stride = w33;
+            p.w_first = c->wd_conv2; p.w_second = c->wd_conv1; p.w_post = c->wd_proj;
+            p.tiles = (const vqa_resblock_tile*)(c->blob + lv.off_fused_bwd); p.num_tiles = lv.count;
+            p.num_post = lv.bcount;
+            p.slot_stride = slot; p.w_group_stride = w33; p.w_pre_group_stride = w11;
             if ((rc = vqa_resblock_tiles(&p, stream))) return rc;
-        } else {
+            continue;
+        }
         {   // dH = dgrad_conv2(dZ) * (H > 0)
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->wd_conv2; p.w_group_stride = w33;
@@ -103,7 +116,6 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
             p.w = c->wd_conv1; p.w_group_stride = w33;
             p.tiles = tiles_at(c, lv.off_dgrad1); p.num_tiles = lv.count;
             if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
-        }
         }
         if (lv.bcount > 0) {   // [dx; dy] = dP * Wproj, each masked by its own child's output
             vqa_conv_params p = base_conv(pl, c);

@@ -358,9 +358,8 @@ class ModuleNet(nn.Module):
         if x.dim() != 4 or tuple(x.shape[1:]) != (d['cin'], 14, 14):
             raise ValueError('features must be [N, %d, 14, 14]' % d['cin'])
         T = program.size(1)
-        pk = self._pack_weights(dev)
         ws = self._pool.acquire()
-        st = _CallState(N=N, pk=pk, ws=ws)
+        st = _CallState(N=N, ws=ws)
         try:
             cur = torch.cuda.current_stream(dev)
             if self._side is None or self._side.device != dev:
@@ -387,6 +386,9 @@ class ModuleNet(nn.Module):
                 hprog.copy_(program.detach().to(torch.int64))
                 arrived = None
 
+            # refreshing the packed weights (after an optimizer step) is device work the host does
+            # not wait for either: it goes behind the program download's starting point
+            st['pk'] = pk = self._pack_weights(dev)
             # stem: two conv3x3 + bias + ReLU over the whole batch (Module_Model.py:55-64,239)
             slot = (HW * c, c)
             stem_elems = 2 * N * HW * c
@@ -405,7 +407,9 @@ class ModuleNet(nn.Module):
             # programs -> plan -> tile lists on the device
             if arrived is not None:
                 arrived.synchronize()
-            plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk)
+            fused = c == 128 and self.fuse_residual_body
+            plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk,
+                        _lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED)
             st['plan'] = plan
             info = plan.info
             self.last_token_counts = plan.token_counts()

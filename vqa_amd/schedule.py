@@ -14,7 +14,7 @@ from . import _lib, vocab as V
 class Plan:
     """Parsed + bucketed programs of one batch.  Owns the native plan handle."""
 
-    def __init__(self, programs, vocab, module_dim=128, wgrad_chunk=16):
+    def __init__(self, programs, vocab, module_dim=128, wgrad_chunk=16, flags=0):
         lib = _lib.load()
         prog = np.ascontiguousarray(np.asarray(programs), dtype=np.int64)
         if prog.ndim != 2:
@@ -26,7 +26,7 @@ class Plan:
         n, t = prog.shape
         _lib.check(lib.vqa_schedule_build(
             prog.ctypes.data_as(_lib.i64p), n, t, arity.ctypes.data_as(_lib.i8p), len(arity),
-            t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk,
+            t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk, flags,
             C.byref(self._h)))
         self.info = _lib.PlanInfo()
         _lib.check(lib.vqa_plan_get_info(self._h, C.byref(self.info)))
