@@ -141,15 +141,20 @@ def main():
         step(i)
     barrier()
     # The roofline figure needs the dominant kernel's launches timed with HIP events inside the
-    # timed region; the two event records per launch cost host time, so only that kind is timed
-    # there.  The other kinds are timed in a few extra steps after the timed region.
+    # timed region.  An event pair around a launch keeps it from overlapping its neighbours and
+    # costs about 5 us, so the launches of every fourth timed step are sampled, and only that
+    # kind; the other kinds are timed in a few extra steps after the timed region.
     dominant = 'resblock' if a.module_dim == 128 else 'conv3x3'
     prof_on = os.environ.get('VQA_BENCH_NO_KERNEL_TIMING') is None
-    ops.prof_enable([dominant] if prof_on else False)
+    sampled_steps = 0
+    ops.prof_enable(False)
     ops.prof_collect()
     t0 = time.perf_counter()
     marks = []
     for i in range(a.steps):
+        if prof_on:
+            ops.prof_enable([dominant] if i % 4 == 0 else False)
+            sampled_steps += i % 4 == 0
         loss = step(a.warmup + i)
         marks.append(time.perf_counter())
         if os.environ.get('VQA_BENCH_VERBOSE') == '2':
@@ -210,9 +215,10 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
-                         'launches': k['launches'], 'avg_launch_ms': k['ms'] / max(k['launches'], 1)},
+                         'launches': k['launches'], 'avg_launch_ms': k['ms'] / max(k['launches'], 1),
+                         'sampled_steps': sampled_steps},
             'kernels': {n: {'launches': v['launches'],
-                            'ms_per_step': v['ms'] / (a.steps if n == dominant else max(extra_steps, 1)),
+                            'ms_per_step': v['ms'] / max(sampled_steps if n == dominant else extra_steps, 1),
                             'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
                         for n, v in prof.items()},
             'loss': float(loss.detach()),

@@ -52,7 +52,8 @@ typedef struct {
     int32_t blob_words;     /* int32 words of the device descriptor blob */
     int32_t wgrad_items;    /* work items of the grouped weight-gradient launch */
     int32_t max_level_tiles;
-    int32_t reserved[3];
+    int32_t wgrad_partial_blocks; /* vqa_tree_backward's workspace, in blocks of 8192 floats */
+    int32_t reserved[2];
 } vqa_plan_info;
 
 /* programs: host int64 [N][T].  arity: int8 [V] (0 scene, 1 unary, 2 binary), indexed by token id
@@ -96,6 +97,7 @@ enum {
     VQA_SEC_SCENE_OFFSETS, VQA_SEC_SCENE_SRC,
     VQA_SEC_WG_ITEMS, VQA_SEC_WG_SRC_C1, VQA_SEC_WG_DY_C1, VQA_SEC_WG_SRC_C2, VQA_SEC_WG_DY_C2,
     VQA_SEC_WG_PITEMS, VQA_SEC_WG_PSRC0, VQA_SEC_WG_PSRC1, VQA_SEC_WG_PDY,
+    VQA_SEC_SAMPLE_ITEMS_FINE, /* as SAMPLE_ITEMS in chunks of max(1, min(wgrad_chunk, N/128)) samples */
     VQA_SEC_COUNT
 };
 int vqa_plan_section(const vqa_plan* plan, int32_t id, int32_t* offset, int32_t* count);
@@ -197,7 +199,10 @@ int vqa_pack_conv_weight(const float* w, void* packed, int32_t groups, int32_t n
  * Grouped weight gradient: dW[group][tap][i][o] += sum over the group's nodes and pixels of
  * src(pixel + tap)[i] * dy(pixel)[o]; db[group][o] += sum dy(pixel)[o].  Replaces autograd's
  * per-call conv weight gradients and their accumulation into the shared per-token weights
- * (Train_model.py:313 over Module_Model.py:221).  fp32 atomic accumulation.
+ * (Train_model.py:313 over Module_Model.py:221).  Two ways out for dW: fp32 atomics into `dw`
+ * (zero it first), or, when `partial` is set, one block of taps * 8192 floats per workgroup
+ * (num_items * n_out/64 * k_chunks blocks), which vqa_wgrad_reduce sums per group into torch's
+ * layout; the second is several times cheaper and deterministic.  db is always atomic.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t group;   /* weight group (token id) */
@@ -213,8 +218,9 @@ typedef struct {
     const int32_t* src_slots;   /* device: per node, source slot (pair: src1_slots too) */
     const int32_t* src1_slots;  /* device or null */
     const int32_t* dy_slots;    /* device */
-    float* dw;                  /* fp32 [groups][taps][k_in][n_out] accumulators */
+    float* dw;                  /* fp32 [groups][taps][k_in][n_out] accumulators (atomic mode) */
     float* db;                  /* fp32 [groups][n_out] or null */
+    float* partial;             /* non-null: partial-block mode, dw is not used */
     int64_t src_slot_stride, dy_slot_stride;
     int64_t dw_group_stride;    /* elements */
     int32_t src_pix_stride, dy_pix_stride;
@@ -227,6 +233,13 @@ typedef struct {
 } vqa_wgrad_params;
 
 int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* stream);
+
+/* out[group][n][k][tap] (torch's OIHW, groups apart by out_g_stride) = sum of the partial blocks
+ * of the group's items; a group without items gets zeros.  items / num_items / n_out / k_chunks as
+ * in the vqa_wgrad_tiles call that wrote `partial`. */
+int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* items, int32_t num_items,
+                     int32_t groups, int32_t n_out, int32_t k_chunks, int32_t taps, float* out,
+                     int64_t out_g_stride, void* stream);
 
 /* dW accumulators [groups][taps][k][n] fp32 -> torch layout [n][k][taps] (OIHW), groups apart by
  * out_g_stride */
@@ -301,8 +314,11 @@ typedef struct {
     const void *w_conv1, *w_conv2, *w_proj;     /* packed forward weights, one group per token */
     const void *wd_conv1, *wd_conv2, *wd_proj;  /* packed input-gradient weights */
     const float *b_conv1, *b_conv2, *b_proj;    /* fp32 [V][C] */
-    float *g_conv1, *g_conv2, *g_proj;          /* fp32 accumulators [V][9][C][C], [V][2C][C] */
-    float *gb_conv1, *gb_conv2, *gb_proj;       /* fp32 [V][C] */
+    float *g_conv1, *g_conv2, *g_proj;          /* out: fp32 weight gradients in torch's layout,
+                                                   [V][C][C][3][3] and [V][C][2C][1][1] (all written) */
+    float *gb_conv1, *gb_conv2, *gb_proj;       /* fp32 [V][C], accumulated into: zero them first */
+    float* wgrad_partial;                       /* workspace of vqa_tree_backward:
+                                                   vqa_plan_info.wgrad_partial_blocks * 8192 floats */
     int32_t C, V;
     int32_t flags;                     /* VQA_TREE_* */
     int32_t reserved;

@@ -289,6 +289,22 @@ def test_wgrad3x3_grouped_accumulates_over_nodes():
         close(out[g], rw, 5e-3)
         close(db[g], rb, 5e-3)
     assert out[1].abs().max() == 0 and db[1].abs().max() == 0
+    # partial-block mode + reduction: same sums (fp32 addition order differs), group 1 written as zeros,
+    # and the same bits on every run
+    part = torch.empty(3 * 2 * 9 * 8192, device=dev())
+    outs = []
+    for _ in range(2):
+        o2 = torch.full((G, C, C, 3, 3), 7.0, device=dev())
+        part.fill_(float('nan'))
+        ops.wgrad_tiles(arena, arena, (items, 0), 3, (src_slots, 0), (dy_slots, 0), None, None, taps=9, k_chunks=1,
+                        n_out=C, src_slot_stride=HW * C, dy_slot_stride=HW * C, src_pix_stride=C,
+                        dy_pix_stride=C, dw_group_stride=9 * C * C, partial=part)
+        ops.wgrad_reduce(part, (items, 0), 3, G, C, 1, 9, o2, C * C * 9)
+        torch.cuda.synchronize()
+        outs.append(o2.cpu())
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0], out, 1e-5)
+    assert outs[0][1].abs().max() == 0
 
 
 def test_wgrad1x1_pair_sources():

@@ -16,8 +16,9 @@ i32p, i64p, i8p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int8
 class PlanInfo(C.Structure):
     _fields_ = [(n, i32) for n in ('N', 'T', 'C', 'num_nodes', 'num_scene', 'num_unary',
                                    'num_binary', 'num_levels', 'slots_fwd', 'slots_total',
-                                   'blob_words', 'wgrad_items', 'max_level_tiles')] + \
-               [('reserved', i32 * 3)]
+                                   'blob_words', 'wgrad_items', 'max_level_tiles',
+                                   'wgrad_partial_blocks')] + \
+               [('reserved', i32 * 2)]
 
 
 class ConvParams(C.Structure):
@@ -30,7 +31,7 @@ class ConvParams(C.Structure):
 
 class WgradParams(C.Structure):
     _fields_ = [('src', vp), ('dy', vp), ('items', vp), ('src_slots', vp), ('src1_slots', vp),
-                ('dy_slots', vp), ('dw', vp), ('db', vp), ('src_slot_stride', i64),
+                ('dy_slots', vp), ('dw', vp), ('db', vp), ('partial', vp), ('src_slot_stride', i64),
                 ('dy_slot_stride', i64), ('dw_group_stride', i64), ('src_pix_stride', i32),
                 ('dy_pix_stride', i32), ('k_chunks', i32), ('pair_chunks', i32), ('n_out', i32),
                 ('num_items', i32), ('total_nodes', i32), ('reserved', i32)]
@@ -48,7 +49,7 @@ class TreeCtx(C.Structure):
                 ('wd_conv1', vp), ('wd_conv2', vp), ('wd_proj', vp),
                 ('b_conv1', vp), ('b_conv2', vp), ('b_proj', vp),
                 ('g_conv1', vp), ('g_conv2', vp), ('g_proj', vp),
-                ('gb_conv1', vp), ('gb_conv2', vp), ('gb_proj', vp),
+                ('gb_conv1', vp), ('gb_conv2', vp), ('gb_proj', vp), ('wgrad_partial', vp),
                 ('C', i32), ('V', i32), ('flags', i32), ('reserved', i32)]
 
 
@@ -63,7 +64,7 @@ SEC = {name: i for i, name in enumerate((
     'STEM0_TILES', 'STEM1_TILES', 'STEM1_DGRAD_TILES', 'CLS_FWD_TILES', 'CLS_DGRAD_TILES',
     'SLOTS_IDENT', 'SLOTS_S0', 'SLOTS_F', 'SLOTS_DF', 'SLOTS_DS0', 'SLOTS_ROOTY', 'SAMPLE_ITEMS',
     'SCENE_OFFSETS', 'SCENE_SRC', 'WG_ITEMS', 'WG_SRC_C1', 'WG_DY_C1', 'WG_SRC_C2', 'WG_DY_C2',
-    'WG_PITEMS', 'WG_PSRC0', 'WG_PSRC1', 'WG_PDY'))}
+    'WG_PITEMS', 'WG_PSRC0', 'WG_PSRC1', 'WG_PDY', 'SAMPLE_ITEMS_FINE'))}
 
 CONV_BIAS, CONV_RELU = 1, 2
 TREE_UNFUSED = 1
@@ -89,6 +90,7 @@ SIGNATURES = {
     'vqa_resblock_tiles': (i32, [C.POINTER(ResblockParams), vp]),
     'vqa_pack_conv_weight': (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp]),
     'vqa_wgrad_tiles': (i32, [C.POINTER(WgradParams), i32, vp]),
+    'vqa_wgrad_reduce': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
     'vqa_unpack_conv_grad': (i32, [vp, vp, i32, i32, i32, i32, i64, vp]),
     'vqa_gemm': (i32, [C.POINTER(GemmParams), vp]),
     'vqa_nchw_to_nhwc': (i32, [vp, vp, i32, i32, i32, vp]),

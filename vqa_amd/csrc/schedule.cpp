@@ -294,6 +294,16 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
         b.insert(b.end(), it, it + 4);
     }
     endsec(VQA_SEC_SAMPLE_ITEMS, nitems);
+    // the same in finer chunks (at least 128 items when N allows), for launches whose grid is
+    // items x 2 only (stem conv 2: 128 source channels) and would otherwise leave most CUs idle
+    sec(VQA_SEC_SAMPLE_ITEMS_FINE);
+    const int fine = std::max(1, std::min(wgrad_chunk, N / 128));
+    nitems = 0;
+    for (int s = 0; s < N; s += fine, nitems++) {
+        const int32_t it[4] = {0, s, std::min(fine, N - s), 0};
+        b.insert(b.end(), it, it + 4);
+    }
+    endsec(VQA_SEC_SAMPLE_ITEMS_FINE, nitems);
 
     // scene fan-in (CSR by sample)
     std::vector<std::vector<int>> scenes(N);
@@ -340,6 +350,15 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
             }
         }
     }
+    // longest items first: workgroups are dispatched in index order as CUs free up, so this is the
+    // greedy longest-processing-time schedule and the launch does not end on a late long item
+    auto by_count = [](std::vector<int32_t>& its) {
+        struct It { int32_t w[4]; };
+        It* a = reinterpret_cast<It*>(its.data());
+        std::stable_sort(a, a + its.size() / 4, [](const It& x, const It& y) { return x.w[2] > y.w[2]; });
+    };
+    by_count(items);
+    by_count(pitems);
     auto put = [&](int id, const std::vector<int32_t>& v, int count) {
         sec(id); b.insert(b.end(), v.begin(), v.end()); endsec(id, count);
     };
@@ -370,6 +389,11 @@ extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
     o->blob_words = (int)pl->blob.size();
     o->wgrad_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
     o->max_level_tiles = pl->max_level_tiles;
+    {   // one block of 8192 floats per tap and workgroup of the largest weight-gradient launch
+        const int cc = pl->C / 128, os = pl->C / 64;
+        o->wgrad_partial_blocks = std::max(pl->sec_cnt[VQA_SEC_WG_ITEMS] * os * cc * 9,
+                                           pl->sec_cnt[VQA_SEC_WG_PITEMS] * os * 2 * cc);
+    }
     return VQA_OK;
 }
 

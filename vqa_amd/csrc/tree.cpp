@@ -1,6 +1,8 @@
 // Level-by-level execution of the whole batch's module trees: the replacement for the per-sample
 // recursion of Module_Model.py:224-233 and for autograd's walk back over it.  Host code; it only
 // fills parameter blocks and enqueues the grouped kernels of conv.hip / wgrad.hip / misc.hip.
+#include <hip/hip_runtime.h>
+
 #include "plan.h"
 
 namespace {
@@ -79,7 +81,7 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
 
 extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void* stream) {
     if (!pl || !c || !c->arena || !c->blob || !c->wd_conv1 || !c->wd_conv2 || !c->g_conv1 || !c->g_conv2 ||
-        !c->gb_conv1 || !c->gb_conv2 || c->C != pl->C ||
+        !c->gb_conv1 || !c->gb_conv2 || !c->wgrad_partial || c->C != pl->C ||
         (pl->num_binary > 0 && (!c->wd_proj || !c->g_proj || !c->gb_proj))) {
         vqa_set_error("vqa_tree_backward: bad argument");
         return VQA_EINVAL;
@@ -141,15 +143,17 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     w.num_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
     w.total_nodes = (int)pl->nodes.size();
     w.k_chunks = cc;
-    w.dw_group_stride = w33;
+    w.partial = c->wgrad_partial;
     w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C1];
     w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C1];
-    w.dw = c->g_conv1; w.db = c->gb_conv1;
+    w.db = c->gb_conv1;
     if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
+    if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv1, w33, stream))) return rc;
     w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C2];
     w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C2];
-    w.dw = c->g_conv2; w.db = c->gb_conv2;
+    w.db = c->gb_conv2;
     if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
+    if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv2, w33, stream))) return rc;
     if (pl->sec_cnt[VQA_SEC_WG_PITEMS] > 0) {
         w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_PITEMS]);
         w.num_items = pl->sec_cnt[VQA_SEC_WG_PITEMS];
@@ -158,9 +162,12 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
         w.src1_slots = c->blob + pl->sec_off[VQA_SEC_WG_PSRC1];
         w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_PDY];
         w.k_chunks = 2 * cc; w.pair_chunks = cc;
-        w.dw_group_stride = w11;
-        w.dw = c->g_proj; w.db = c->gb_proj;
+        w.db = c->gb_proj;
         if ((rc = vqa_wgrad_tiles(&w, 1, stream))) return rc;
+        if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, 2 * cc, 1, c->g_proj, w11, stream))) return rc;
+    } else if (c->g_proj) {
+        hipError_t e = hipMemsetAsync(c->g_proj, 0, (size_t)c->V * w11 * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) { vqa_set_error("vqa_tree_backward: memset failed"); return VQA_ELAUNCH; }
     }
     return VQA_OK;
 }

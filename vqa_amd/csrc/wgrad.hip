@@ -1,4 +1,5 @@
-// Grouped convolution weight gradient (gfx950, bf16 MFMA, fp32 atomic accumulation).
+// Grouped convolution weight gradient (gfx950, bf16 MFMA; per-workgroup partial sums + a reduction
+// pass, or fp32 atomic accumulation).
 //
 //   dW[group][tap][i][o] += sum_{node in group} sum_{pixel} src_node(pixel + tap)[i] * dy_node(pixel)[o]
 //
@@ -7,7 +8,11 @@
 // (8 waves) owns a work item (<= wgrad_chunk nodes of one weight group) x 64 output channels x
 // 128 source channels; wave w owns source channels [16w, 16w+16) x 4 tiles of 16 output channels x
 // every tap, so its accumulators (taps x 4 tiles) stay in registers across all nodes of the item
-// and leave once, as fp32 atomics.  A k-step of 32 is two image rows of 16 columns; columns 14, 15
+// and leave once.  Leaving as fp32 atomics keeps a CU busy for ~60 us per workgroup (one 256-byte
+// atomic instruction per ~50 ns per CU) with nothing else resident to hide it; leaving as plain
+// 16-byte stores into a per-workgroup partial block costs a few us, and vqa_wgrad_reduce then sums
+// the blocks of each group straight into torch's weight layout (which also makes the result
+// independent of the order workgroups finish in).  A k-step of 32 is two image rows of 16 columns; columns 14, 15
 // of the dy image are zero, the source image has a zero border.
 //
 // Replaces autograd's per-call conv weight/bias gradients and their sum over every use of a
@@ -137,18 +142,28 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
     }
 
     // accumulators out: row = source channel, col = output channel
-    const int k_in = p.k_chunks * 128;
-    float* dw = p.dw + (int64_t)it.group * p.dw_group_stride;
+    if (p.partial) {
+        // block of this workgroup: [tap][64 output channels][128 source channels] fp32
+        float* part = p.partial + ((int64_t)(blockIdx.x * gridDim.y + oslice) * gridDim.z + kchunk) * (TAPS * 8192);
 #pragma unroll
-    for (int t = 0; t < TAPS; t++)
+        for (int t = 0; t < TAPS; t++)
 #pragma unroll
-        for (int o = 0; o < 4; o++)
+            for (int o = 0; o < 4; o++)
+                *(f32x4*)(part + (t * 64 + o * 16 + l15) * 128 + wave * 16 + g * 4) = acc[t][o];
+    } else {
+        const int k_in = p.k_chunks * 128;
+        float* dw = p.dw + (int64_t)it.group * p.dw_group_stride;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int i = kchunk * 128 + wave * 16 + g * 4 + r;
-                const int oc = oslice * 64 + o * 16 + l15;
-                atomicAdd(dw + ((int64_t)t * k_in + i) * p.n_out + oc, acc[t][o][r]);
-            }
+        for (int t = 0; t < TAPS; t++)
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = kchunk * 128 + wave * 16 + g * 4 + r;
+                    const int oc = oslice * 64 + o * 16 + l15;
+                    atomicAdd(dw + ((int64_t)t * k_in + i) * p.n_out + oc, acc[t][o][r]);
+                }
+    }
 
     if (p.db && kchunk == 0) {
         __syncthreads();
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
 }
 
 extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* stream) {
-    if (!p || !p->src || !p->dy || !p->items || !p->src_slots || !p->dy_slots || !p->dw ||
+    if (!p || !p->src || !p->dy || !p->items || !p->src_slots || !p->dy_slots || (!p->dw && !p->partial) ||
         (taps != 9 && taps != 1) || p->k_chunks <= 0 || p->n_out <= 0 || p->n_out % 64 != 0 ||
         p->src_pix_stride % 8 != 0 || p->dy_pix_stride % 8 != 0 || p->num_items < 0 ||
         (p->pair_chunks > 0 && !p->src1_slots)) {
@@ -188,6 +203,51 @@ extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* st
     else hipLaunchKernelGGL(wgrad_tiles_kernel<1>, grid, block, WGRAD_LDS, (hipStream_t)stream, *p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_wgrad_tiles: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}
+
+// Sum the partial blocks of vqa_wgrad_tiles per weight group, writing torch's [n][k][tap] layout.
+// A thread owns one (output channel, source channel) pair and all taps; the threads of a block
+// share the group, so the scan over the item list is uniform.
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                           const vqa_wgrad_item* __restrict__ items, int num_items,
+                                                           int n_out, int k_chunks, float* __restrict__ out,
+                                                           int64_t out_g_stride) {
+    const int grp = blockIdx.y, k_in = k_chunks * 128;
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // oc * k_in + i
+    const int oc = idx / k_in, i = idx - oc * k_in;
+    const int oslice = oc >> 6, ocl = oc & 63, kchunk = i >> 7, il = i & 127;
+    const int oslices = n_out >> 6;
+    float acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; t++) acc[t] = 0.f;
+    for (int j = 0; j < num_items; j++) {
+        if (items[j].group != grp) continue;
+        const float* part = partial + ((int64_t)(j * oslices + oslice) * k_chunks + kchunk) * (TAPS * 8192) + ocl * 128 + il;
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) acc[t] += part[t * 8192];
+    }
+    float* o = out + (int64_t)grp * out_g_stride + (int64_t)idx * TAPS;
+#pragma unroll
+    for (int t = 0; t < TAPS; t++) o[t] = acc[t];
+}
+
+extern "C" int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* items, int32_t num_items,
+                                int32_t groups, int32_t n_out, int32_t k_chunks, int32_t taps, float* out,
+                                int64_t out_g_stride, void* stream) {
+    if (!partial || !items || !out || num_items < 0 || groups <= 0 || n_out <= 0 || n_out % 64 != 0 ||
+        k_chunks <= 0 || (taps != 9 && taps != 1)) {
+        vqa_set_error("vqa_wgrad_reduce: bad argument");
+        return VQA_EINVAL;
+    }
+    dim3 grid(n_out * k_chunks * 128 / 256, groups), block(256);
+    if (taps == 9) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, grid, block, 0, (hipStream_t)stream, partial, items,
+                                      num_items, n_out, k_chunks, out, out_g_stride);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, grid, block, 0, (hipStream_t)stream, partial, items,
+                            num_items, n_out, k_chunks, out, out_g_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_wgrad_reduce: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;
 }
 

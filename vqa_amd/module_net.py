@@ -575,29 +575,30 @@ class ModuleNet(nn.Module):
         # ---- classifier conv1x1: weight/bias gradient, then gradient into the roots' dZ slots
         it_off, it_cnt = plan.section('SAMPLE_ITEMS')
         sec = lambda n: (blob, plan.section(n)[0])
-        gcw = torch.zeros(1, 1, c, p_, **f32)
         gcb = torch.zeros(p_, **f32)
-        ops.wgrad_tiles(arena, dc1, (blob, it_off), it_cnt, sec('SLOTS_ROOTY'), sec('SLOTS_IDENT'), gcw, gcb,
+        info = plan.info
+        need_blocks = max(info.wgrad_partial_blocks, it_cnt * (p_ // 64) * (c // 128),
+                          it_cnt * (c // 64) * (cpad // 128) * 9,
+                          plan.section('SAMPLE_ITEMS_FINE')[1] * (c // 64) * (c // 128) * 9)
+        part = ws.get('wg_partial', need_blocks * 8192, torch.float32, dev)
+        ops.wgrad_tiles(arena, dc1, (blob, it_off), it_cnt, sec('SLOTS_ROOTY'), sec('SLOTS_IDENT'), None, gcb,
                         taps=1, k_chunks=c // 128, n_out=p_, src_slot_stride=HW * c, dy_slot_stride=HW * p_,
-                        src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_, total_nodes=N)
+                        src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_, total_nodes=N, partial=part)
         gw = torch.empty(p_, c, 1, 1, **f32)
-        ops.unpack_conv_grad(gcw, gw, 1, p_, c, 1, 0)
+        ops.wgrad_reduce(part, (blob, it_off), it_cnt, 1, p_, c // 128, 1, gw, 0)
         grads['classifier.0.weight'], grads['classifier.0.bias'] = gw, gcb
         self._conv(st, dc1, arena, pk['wd_cls'], 'CLS_DGRAD_TILES', 1, p_ // 128, c, (HW * p_, p_), slot,
                    mask=arena)
 
         # ---- module trees: input gradients by level, scene fan-in, all weight gradients
-        acc = {'g_conv1': torch.zeros(nv, 9, c, c, **f32), 'g_conv2': torch.zeros(nv, 9, c, c, **f32),
-               'g_proj': torch.zeros(nv, 2 * c, c, **f32), 'gb_conv1': torch.zeros(nv, c, **f32),
-               'gb_conv2': torch.zeros(nv, c, **f32), 'gb_proj': torch.zeros(nv, c, **f32)}
-        tctx = self._tree_ctx(st, pk, acc)
-        _lib.check(lib.vqa_tree_backward(plan.handle, C.byref(tctx), ops._stream()))
         gw1 = torch.empty(nv, c, c, 3, 3, **f32)
         gw2 = torch.empty(nv, c, c, 3, 3, **f32)
         gwp = torch.empty(nv, c, 2 * c, 1, 1, **f32)
-        ops.unpack_conv_grad(acc['g_conv1'], gw1, nv, c, c, 9, c * c * 9)
-        ops.unpack_conv_grad(acc['g_conv2'], gw2, nv, c, c, 9, c * c * 9)
-        ops.unpack_conv_grad(acc['g_proj'], gwp, nv, c, 2 * c, 1, 2 * c * c)
+        acc = {'g_conv1': gw1, 'g_conv2': gw2, 'g_proj': gwp, 'gb_conv1': torch.zeros(nv, c, **f32),
+               'gb_conv2': torch.zeros(nv, c, **f32), 'gb_proj': torch.zeros(nv, c, **f32)}
+        tctx = self._tree_ctx(st, pk, acc)
+        tctx.wgrad_partial = part.data_ptr()
+        _lib.check(lib.vqa_tree_backward(plan.handle, C.byref(tctx), ops._stream()))
         counts = plan.token_counts()
         for i, tok in enumerate(self._tokens):
             if counts[i] == 0:
@@ -609,19 +610,19 @@ class ModuleNet(nn.Module):
 
         # ---- stem: dS0 = dgrad(dF) * (S0 > 0); weight gradients of both convs (no d/dx)
         self._conv(st, arena, arena, pk['wd_stem1'], 'STEM1_DGRAD_TILES', 9, c // 128, c, slot, slot, mask=arena)
-        gs1, gs1b = torch.zeros(1, 9, c, c, **f32), torch.zeros(c, **f32)
-        ops.wgrad_tiles(arena, arena, (blob, it_off), it_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), gs1, gs1b,
+        gs1b, gs0b = torch.zeros(c, **f32), torch.zeros(c, **f32)
+        fi_off, fi_cnt = plan.section('SAMPLE_ITEMS_FINE')
+        ops.wgrad_tiles(arena, arena, (blob, fi_off), fi_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), None, gs1b,
                         taps=9, k_chunks=c // 128, n_out=c, src_slot_stride=HW * c, dy_slot_stride=HW * c,
-                        src_pix_stride=c, dy_pix_stride=c, dw_group_stride=9 * c * c, total_nodes=N)
-        gs0, gs0b = torch.zeros(1, 9, cpad, c, **f32), torch.zeros(c, **f32)
-        ops.wgrad_tiles(st['x_nhwc'], arena, (blob, it_off), it_cnt, sec('SLOTS_IDENT'), sec('SLOTS_DS0'), gs0, gs0b,
-                        taps=9, k_chunks=cpad // 128, n_out=c, src_slot_stride=HW * cpad, dy_slot_stride=HW * c,
-                        src_pix_stride=cpad, dy_pix_stride=c, dw_group_stride=9 * cpad * c, total_nodes=N)
+                        src_pix_stride=c, dy_pix_stride=c, dw_group_stride=9 * c * c, total_nodes=N, partial=part)
         gw = torch.empty(c, c, 3, 3, **f32)
-        ops.unpack_conv_grad(gs1, gw, 1, c, c, 9, 0)
+        ops.wgrad_reduce(part, (blob, fi_off), fi_cnt, 1, c, c // 128, 9, gw, 0)
         grads['stem.2.weight'], grads['stem.2.bias'] = gw, gs1b
+        ops.wgrad_tiles(st['x_nhwc'], arena, (blob, it_off), it_cnt, sec('SLOTS_IDENT'), sec('SLOTS_DS0'), None, gs0b,
+                        taps=9, k_chunks=cpad // 128, n_out=c, src_slot_stride=HW * cpad, dy_slot_stride=HW * c,
+                        src_pix_stride=cpad, dy_pix_stride=c, dw_group_stride=9 * cpad * c, total_nodes=N, partial=part)
         gw = torch.empty(c, cpad, 3, 3, **f32)
-        ops.unpack_conv_grad(gs0, gw, 1, c, cpad, 9, 0)
+        ops.wgrad_reduce(part, (blob, it_off), it_cnt, 1, c, cpad // 128, 9, gw, 0)
         grads['stem.0.weight'] = gw[:, :d['cin']].contiguous() if cpad != d['cin'] else gw
         grads['stem.0.bias'] = gs0b
 

@@ -80,21 +80,32 @@ def pack_conv_weight(w, groups, n_out, k_in, taps, g_stride, n_stride, k_stride,
 
 def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps, k_chunks, n_out,
                 src_slot_stride, dy_slot_stride, src_pix_stride, dy_pix_stride, dw_group_stride,
-                src1_slots=None, pair_chunks=0, total_nodes=0):
-    """items / *_slots are (tensor, word_offset) pairs into an int32 device blob."""
+                src1_slots=None, pair_chunks=0, total_nodes=0, partial=None):
+    """items / *_slots are (tensor, word_offset) pairs into an int32 device blob.  With `partial`
+    (fp32 workspace of num_items * n_out/64 * k_chunks * taps * 8192 elements) the workgroups store
+    partial blocks for wgrad_reduce and `dw` may be None; otherwise they add into `dw` atomically."""
     p = _lib.WgradParams()
     p.src, p.dy = src.data_ptr(), dy.data_ptr()
     p.items = items[0].data_ptr() + 4 * items[1]
     p.src_slots = src_slots[0].data_ptr() + 4 * src_slots[1]
     p.src1_slots = (src1_slots[0].data_ptr() + 4 * src1_slots[1]) if src1_slots is not None else 0
     p.dy_slots = dy_slots[0].data_ptr() + 4 * dy_slots[1]
-    p.dw = dw.data_ptr()
+    p.dw = dw.data_ptr() if dw is not None else 0
+    if partial is not None:
+        assert partial.numel() >= num_items * (n_out // 64) * k_chunks * taps * 8192
+        p.partial = partial.data_ptr()
     p.db = db.data_ptr() if db is not None else 0
     p.src_slot_stride, p.dy_slot_stride, p.dw_group_stride = src_slot_stride, dy_slot_stride, dw_group_stride
     p.src_pix_stride, p.dy_pix_stride = src_pix_stride, dy_pix_stride
     p.k_chunks, p.pair_chunks, p.n_out, p.num_items = k_chunks, pair_chunks, n_out, num_items
     p.total_nodes = total_nodes
     _lib.check(_lib.load().vqa_wgrad_tiles(C.byref(p), taps, _stream()))
+
+
+def wgrad_reduce(partial, items, num_items, groups, n_out, k_chunks, taps, out, out_g_stride):
+    """out[group][n][k][tap] = sum of the group's partial blocks (see wgrad_tiles)."""
+    _lib.check(_lib.load().vqa_wgrad_reduce(_ptr(partial), items[0].data_ptr() + 4 * items[1], num_items, groups,
+                                            n_out, k_chunks, taps, _ptr(out), out_g_stride, _stream()))
 
 
 def unpack_conv_grad(dw, out, groups, n_out, k_in, taps, out_g_stride):
