@@ -64,6 +64,11 @@ typedef struct {
  * paths can leave the other's lists out, which halves the blob. */
 #define VQA_PLAN_SKIP_SEPARATE 1
 #define VQA_PLAN_SKIP_FUSED 2
+/* levels: by default a node's level is 1 + its deepest child's (the earliest it can run).  With
+ * VQA_PLAN_BALANCE nodes that have slack are moved to later levels so that the launches of a level
+ * come in whole rounds of the device (256 CUs x 2 workgroups); the level count, node ids, slots and
+ * results stay the same. */
+#define VQA_PLAN_BALANCE 4
 int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T, const int8_t* arity,
                        int32_t V, int32_t null_id, int32_t start_id, int32_t scene_id, int32_t C,
                        int32_t wgrad_chunk, int32_t flags, vqa_plan** out);
@@ -184,6 +189,8 @@ typedef struct {
     int32_t num_tiles;
     int32_t num_pre, num_post;  /* how many tiles have a pre / post part (work accounting and
                                    argument checks; the kernel decides per tile) */
+    unsigned long long* phase_stamps; /* diagnostics: null, or device [num_tiles][8] shader-clock
+                                   timestamps of each tile's phase boundaries */
 } vqa_resblock_params;
 
 int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);

@@ -127,3 +127,31 @@ def test_flops_formula(vocab):
     fixed = 462422016 + 57802752 + 25690112 + 205520896 + 65536
     assert fwd == 64 * fixed + (i.num_scene + i.num_unary) * 115605504 + i.num_binary * 128450560
     assert both == 3 * fwd - 64 * 462422016
+
+
+def test_balanced_levels_are_a_valid_schedule(vocab):
+    """VQA_PLAN_BALANCE only moves nodes with slack to later levels: same nodes, ids and level
+    count; every child still runs in an earlier level than its parent; levels come in whole or half
+    rounds of 512 tiles except where nodes were due."""
+    from vqa_amd import _lib
+    prog = synth.synth_programs(77, 300, vocab)
+    p0 = Plan(prog, vocab)
+    p1 = Plan(prog, vocab, flags=_lib.PLAN_BALANCE)
+    n0, n1 = p0.nodes(), p1.nodes()
+    np.testing.assert_array_equal(n0[:, :5], n1[:, :5])
+    assert p0.info.num_levels == p1.info.num_levels
+    lv = n1[:, 5]
+    assert (lv >= n0[:, 5]).all()                       # never earlier than the earliest level
+    for v in range(len(n1)):
+        for c in n1[v, 3:5]:
+            if c >= 0:
+                assert lv[c] < lv[v]
+    sizes = np.bincount(lv, minlength=p1.info.num_levels)
+    assert sizes.sum() == len(n1) and (sizes > 0).all()
+    assert sizes.max() < np.bincount(n0[:, 5]).max()
+    for L in range(p1.info.num_levels):
+        ids = p1.level_nodes(L)
+        assert sorted(ids.tolist()) == np.nonzero(lv == L)[0].tolist()
+        toks = n1[ids, 1]
+        assert (np.diff(toks) >= 0).all()               # still grouped by token inside a level
+    np.testing.assert_array_equal(p0.used_fns(), p1.used_fns())

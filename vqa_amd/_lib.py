@@ -57,7 +57,8 @@ class ResblockParams(C.Structure):
     _fields_ = [('arena', vp), ('w_first', vp), ('w_second', vp), ('w_pre', vp), ('w_post', vp),
                 ('bias_first', vp), ('bias_second', vp), ('bias_pre', vp), ('tiles', vp),
                 ('slot_stride', i64), ('w_group_stride', i64), ('w_pre_group_stride', i64),
-                ('flags', i32), ('num_tiles', i32), ('num_pre', i32), ('num_post', i32)]
+                ('flags', i32), ('num_tiles', i32), ('num_pre', i32), ('num_post', i32),
+                ('phase_stamps', vp)]
 
 
 SEC = {name: i for i, name in enumerate((
@@ -68,7 +69,7 @@ SEC = {name: i for i, name in enumerate((
 
 CONV_BIAS, CONV_RELU = 1, 2
 TREE_UNFUSED = 1
-PLAN_SKIP_SEPARATE, PLAN_SKIP_FUSED = 1, 2
+PLAN_SKIP_SEPARATE, PLAN_SKIP_FUSED, PLAN_BALANCE = 1, 2, 4
 
 # name -> (restype, argtypes); every symbol include/vqa_amd.h declares
 SIGNATURES = {

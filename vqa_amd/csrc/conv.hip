@@ -31,29 +31,35 @@
 // Building blocks shared by the single-conv kernel and the fused residual-body kernel
 // ---------------------------------------------------------------------------------------------
 
-// zero the border of the halo image (interior positions are overwritten by every staging pass)
+// zero the border of the halo image: the 68 positions no staging pass ever writes (row 0, columns
+// 0 and 15 of rows 1..14, rows 15 and 16)
 __device__ __forceinline__ void halo_zero_border(char* halo, int tid) {
-    for (int idx = tid; idx < HALO_POS * 16; idx += 256) {
-        const int pos = idx >> 4, row = pos >> 4, col = pos & 15;
-        if (row == 0 || row >= 15 || col == 0 || col == 15)
-            *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+    for (int idx = tid; idx < 68 * 16; idx += 256) {
+        const int j = idx >> 4;
+        int pos;
+        if (j < 16) pos = j;
+        else if (j < 44) pos = (((j - 16) >> 1) + 1) * 16 + ((j & 1) ? 15 : 0);
+        else pos = 240 + (j - 44);
+        *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
     }
 }
 
 // copy one 128-channel chunk of a source map (196 pixels x 256 B) into the halo image interior,
-// through registers, 7 16-byte pieces per thread at a time
+// through registers, BATCH 16-byte pieces per thread at a time (all 13 in flight at once where the
+// accumulators are not live yet, 7 where they are)
+template <int BATCH = 7>
 __device__ __forceinline__ void halo_stage(char* halo, const char* sp, int pix_stride_bytes, int tid, bool diag_noload) {
 #pragma unroll 1
-    for (int i0 = 0; i0 < 14; i0 += 7) {
-        uint4 v[7];
+    for (int i0 = 0; i0 < 13; i0 += BATCH) {
+        uint4 v[BATCH];
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
+        for (int i = 0; i < BATCH; i++) {
             const int e = tid + 256 * (i0 + i), pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
             if (diag_noload) v[i] = make_uint4(e, pix, pc, 0);
             else v[i] = *(const uint4*)(sp + (int64_t)pix * pix_stride_bytes + pc * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
+        for (int i = 0; i < BATCH; i++) {
             const int e = tid + 256 * (i0 + i), pix = e >> 4, pc = e & 15;
             if (pix < VQA_HW) {
                 const int y = pix / 14, x = pix - y * 14;
@@ -67,8 +73,9 @@ __device__ __forceinline__ void halo_stage(char* halo, const char* sp, int pix_s
 // tiles.  Weights come through the 4-slot register ring `wr` (refilled for K-step s+4 after use,
 // so three K-steps of MFMAs cover the L2 latency); pixel fragments through an 8-deep ring read 7
 // tiles ahead; the issue order is pinned to 1 LDS read : 2 MFMA (left alone, the scheduler collapses
-// the ring and waits on every read right after issuing it).
-template <int TAPS>
+// the ring and waits on every read right after issuing it).  With ZERO the accumulators start from
+// the first K-step's products (C operand = inline 0) instead of from registers somebody cleared.
+template <int TAPS, bool ZERO>
 __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[MT], const char* wbase, int64_t wstep,
                                            int nsteps, int& s, bf16x8 (&wr)[4][2], f32x4 (&acc)[MT][2], bool diag_now) {
     bf16x8 xq[8];
@@ -77,8 +84,8 @@ __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[
 #pragma unroll
         for (int q = 0; q < 7; q++) xq[q] = *(const bf16x8*)(x0 + xaddr[q]);
     }
-#pragma unroll 1
-    for (int tap = 0; tap < TAPS; tap++) {
+    auto tap_body = [&](int tap, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const int tapoff = (TAPS == 9) ? ((tap / 3) * 16 + (tap % 3)) : 17;
         const int tn = (tap + 1 < TAPS) ? tap + 1 : tap;      // last tap: harmless re-read
         const int tapoff_n = (TAPS == 9) ? ((tn / 3) * 16 + (tn % 3)) : 17;
@@ -92,8 +99,14 @@ __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[
                 const int qa = q + 7;                 // fragment to fetch now
                 const int ka = (qa / MT) & 3, ma = qa % MT;
                 xq[qa & 7] = *(const bf16x8*)((qa < 4 * MT ? xb : xn) + xaddr[ma] + ka * 64);
-                acc[m][0] = mma16(wr[ks][0], xq[q & 7], acc[m][0]);
-                acc[m][1] = mma16(wr[ks][1], xq[q & 7], acc[m][1]);
+                if (FIRST && ks == 0) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    acc[m][0] = mma16(wr[ks][0], xq[q & 7], z);
+                    acc[m][1] = mma16(wr[ks][1], xq[q & 7], z);
+                } else {
+                    acc[m][0] = mma16(wr[ks][0], xq[q & 7], acc[m][0]);
+                    acc[m][1] = mma16(wr[ks][1], xq[q & 7], acc[m][1]);
+                }
             }
 #pragma unroll
             for (int m = 0; m < MT; m++) {
@@ -105,80 +118,67 @@ __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[
             wr[ks][1] = *(const bf16x8*)(wbase + sn * wstep + 1024);
             __builtin_amdgcn_sched_barrier(0);   // keep the refill here: sunk to the loop end it is waited on at once
         }
-    }
+    };
+    if (ZERO) tap_body(0, std::true_type{});
+#pragma unroll 1
+    for (int tap = ZERO ? 1 : 0; tap < TAPS; tap++) tap_body(tap, std::false_type{});
 }
 
 // Final epilogue.  A lane holds pixel (m, l15) x 4 channels, i.e. 8-byte pieces scattered over 14
 // cache lines per instruction; written, or worse read (residual, mask), that way the epilogue costs
-// more than the K loop.  So the accumulators go through LDS (fp32, 7 image rows at a time, the halo
-// image is dead by now) and come back pixel-major: every global access is 16 bytes per lane,
-// 1 KiB contiguous per wave.   out = [relu]( acc + bias + res ) * (mask > 0)
+// more than the K loop.  So the raw accumulators go through LDS (fp32, 7 image rows at a time, the
+// halo image is dead by now) and come back pixel-major: every global access is 16 bytes per lane,
+// 1 KiB contiguous per wave, and bias, residual, rounding, ReLU and mask are applied there, two
+// channels per instruction.   out = [relu]( acc + bias + res ) * (mask > 0)
 __device__ __forceinline__ void conv_epilogue(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
                                               const char* rsrc, const char* msrc, char* dptr, int pix_stride,
                                               int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-    float4 bv[2];
+    const int pc = tid & 15;            // this thread's 16-byte column of every row: channels 8*pc..8*pc+7
+    f32x2 bv[4];
 #pragma unroll
-    for (int n = 0; n < 2; n++)
-        bv[n] = bias ? *(const float4*)(bias + wave * 32 + n * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 4; j++) bv[j] = bias ? *(const f32x2*)(bias + pc * 8 + 2 * j) : (f32x2){0.f, 0.f};
     float* stg = (float*)halo;          // [98 pixels][132 floats]: 528-byte rows keep the writes conflict-free
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
-        // this thread's 16-byte pieces of the half: piece e -> pixel 98*half + (e >> 4), channels 8*(e & 15)..+7
+        // this thread's 16-byte pieces of the half: piece e -> pixel 98*half + (e >> 4)
         uint4 rv[7], mv[7];
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            const int e = tid + 256 * i, pl = min(e >> 4, 97), pc = e & 15;
+            const int pl = min((tid >> 4) + 16 * i, 97);
             const int64_t goff = ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2;
             if (rsrc) rv[i] = *(const uint4*)(rsrc + goff);
             if (msrc) mv[i] = *(const uint4*)(msrc + goff);
         }
-        __syncthreads();     // K loop reads (half 0) / previous half's staging reads are done
+        lds_barrier();       // K loop reads (half 0) / previous half's staging reads are done
         if (l15 < 14) {
 #pragma unroll
             for (int mm = 0; mm < 7; mm++) {
-                const f32x4 a0 = half ? acc[7 + mm][0] : acc[mm][0];
-                const f32x4 a1 = half ? acc[7 + mm][1] : acc[mm][1];
                 float* row = stg + (mm * 14 + l15) * 132 + wave * 32 + lq * 4;
-                *(float4*)(row) = make_float4(a0[0] + bv[0].x, a0[1] + bv[0].y, a0[2] + bv[0].z, a0[3] + bv[0].w);
-                *(float4*)(row + 16) = make_float4(a1[0] + bv[1].x, a1[1] + bv[1].y, a1[2] + bv[1].z, a1[3] + bv[1].w);
+                *(f32x4*)(row) = half ? acc[7 + mm][0] : acc[mm][0];
+                *(f32x4*)(row + 16) = half ? acc[7 + mm][1] : acc[mm][1];
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            const int e = tid + 256 * i, pl = e >> 4, pc = e & 15;
+            const int pl = (tid >> 4) + 16 * i;
             if (pl < 98) {
-                const float4 f0 = *(const float4*)(stg + pl * 132 + pc * 8);
-                const float4 f1 = *(const float4*)(stg + pl * 132 + pc * 8 + 4);
-                float o[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                if (rsrc) {
-                    const uint32_t r[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+                const f32x4 f0 = *(const f32x4*)(stg + pl * 132 + pc * 8);
+                const f32x4 f1 = *(const f32x4*)(stg + pl * 132 + pc * 8 + 4);
+                f32x2 o[4] = {{f0[0], f0[1]}, {f0[2], f0[3]}, {f1[0], f1[1]}, {f1[2], f1[3]}};
+                const uint32_t r[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+                const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
+                uint32_t w[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        o[2 * j] += __uint_as_float(r[j] << 16);
-                        o[2 * j + 1] += __uint_as_float(r[j] & 0xFFFF0000u);
-                    }
+                for (int j = 0; j < 4; j++) {
+                    o[j] += bv[j];
+                    if (rsrc) o[j] += unpack_pk_bf16(r[j]);
+                    w[j] = cvt_pk_bf16(o[j]);
+                    if (relu) w[j] = relu_pk_bf16(w[j]);
+                    if (msrc) w[j] = mask_pk_bf16(w[j], k[j]);
                 }
-                if (relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) o[j] = fmaxf(o[j], 0.f);
-                }
-                if (msrc) {
-                    // a bf16 is positive iff its 16 bits, read as a signed integer, are > 0
-                    const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        o[2 * j] = ((int16_t)(k[j] & 0xFFFF) > 0) ? o[2 * j] : 0.f;
-                        o[2 * j + 1] = ((int16_t)(k[j] >> 16) > 0) ? o[2 * j + 1] : 0.f;
-                    }
-                }
-                uint4 ov;
-                ov.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-                ov.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-                ov.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
-                ov.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
-                *(uint4*)(dptr + ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2) = ov;
+                *(uint4*)(dptr + ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2) = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
     }
@@ -206,11 +206,6 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
     halo_zero_border(halo, tid);
 
     f32x4 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
     // LDS byte offset of this lane's pixel in every pixel tile, at tap (-1,-1), K-chunk lq
     // (lanes 14, 15 read halo padding; their results are discarded)
     int xaddr[MT];
@@ -226,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         __syncthreads();   // every wave is done reading the previous chunk's image
         halo_stage(halo, sp, p.src_pix_stride * 2, tid, (p.flags & 0x400) != 0);
         __syncthreads();
-        conv_kloop<TAPS>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, (p.flags & 0x200) != 0);
+        if (c == 0) conv_kloop<TAPS, true>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, (p.flags & 0x200) != 0);
+        else conv_kloop<TAPS, false>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, (p.flags & 0x200) != 0);
     }
 
     if (p.flags & 0x100) {   // diagnostic: skip the epilogue
@@ -264,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 // ---------------------------------------------------------------------------------------------
 
 // accumulators (+ bias, ReLU) -> bf16 -> interior of the halo image; then a row-wise pass applies
-// an optional mask, rewrites the image and stores the map to `dst` in 16-byte pieces.  Clears acc.
-__device__ __forceinline__ void acc_to_image(char* halo, f32x4 (&acc)[MT][2], const float* bias, bool relu,
+// an optional mask, rewrites the image and stores the map to `dst` in 16-byte pieces.
+__device__ __forceinline__ void acc_to_image(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
                                              const char* mask, char* dst, int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     uint4 mv[13];
@@ -276,29 +272,24 @@ __device__ __forceinline__ void acc_to_image(char* halo, f32x4 (&acc)[MT][2], co
             mv[i] = *(const uint4*)(mask + pix * 256 + pc * 16);
         }
     }
-    __syncthreads();        // every wave has finished reading the image
+    lds_barrier();          // every wave has finished reading the image
     if (l15 < 14) {
 #pragma unroll
         for (int n = 0; n < 2; n++) {
             const int ch = wave * 32 + n * 16 + lq * 4;
-            const float4 bv = bias ? *(const float4*)(bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const f32x2 b0 = bias ? *(const f32x2*)(bias + ch) : (f32x2){0.f, 0.f};
+            const f32x2 b1 = bias ? *(const f32x2*)(bias + ch + 2) : (f32x2){0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-                float o0 = acc[m][n][0] + bv.x, o1 = acc[m][n][1] + bv.y, o2 = acc[m][n][2] + bv.z, o3 = acc[m][n][3] + bv.w;
-                if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
                 uint2 pk;
-                pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-                pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+                pk.x = cvt_pk_bf16((f32x2){acc[m][n][0], acc[m][n][1]} + b0);
+                pk.y = cvt_pk_bf16((f32x2){acc[m][n][2], acc[m][n][3]} + b1);
+                if (relu) { pk.x = relu_pk_bf16(pk.x); pk.y = relu_pk_bf16(pk.y); }
                 *(uint2*)(halo + ((m + 1) * 16 + l15 + 1) * HALO_STRIDE + ch * 2) = pk;
             }
         }
     }
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < 13; i++) {
         const int e = tid + 256 * i, pix = e >> 4, pc = e & 15;
@@ -307,20 +298,14 @@ __device__ __forceinline__ void acc_to_image(char* halo, f32x4 (&acc)[MT][2], co
             uint4* cell = (uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16);
             uint4 v = *cell;
             if (mask) {
-                const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
-                uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (!((int16_t)(k[j] & 0xFFFF) > 0)) w4[j] &= 0xFFFF0000u;
-                    if (!((int16_t)(k[j] >> 16) > 0)) w4[j] &= 0x0000FFFFu;
-                }
-                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                v = make_uint4(mask_pk_bf16(v.x, mv[i].x), mask_pk_bf16(v.y, mv[i].y), mask_pk_bf16(v.z, mv[i].z),
+                               mask_pk_bf16(v.w, mv[i].w));
                 *cell = v;
             }
             *(uint4*)(dst + pix * 256 + pc * 16) = v;
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase, int64_t wstep) {
@@ -336,6 +321,10 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const vqa_resblock_tile t = p.tiles[blockIdx.x];
+    // diagnostics: shader-clock timestamps of the phase boundaries of every tile
+    unsigned long long* stamps = p.phase_stamps ? p.phase_stamps + (int64_t)blockIdx.x * 8 : nullptr;
+#define STAMP(i) if (stamps && tid == 0) stamps[i] = __builtin_readcyclecounter()
+    STAMP(0);
     const int64_t slot_b = p.slot_stride * 2;       // bytes per slot; pixel stride is 256 B (C = 128)
     char* arena = (char*)p.arena;
     const bool relu = (p.flags & VQA_CONV_RELU) != 0, has_bias = (p.flags & VQA_CONV_BIAS) != 0;
@@ -350,31 +339,32 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     load_wring(wr, wbase, wstep);
     halo_zero_border(halo, tid);
     f32x4 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
     int xaddr[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
 
-    halo_stage(halo, arena + (int64_t)t.src0 * slot_b, 256, tid, false);
+    halo_stage<7>(halo, arena + (int64_t)t.src0 * slot_b, 256, tid, false);
     __syncthreads();
+    STAMP(1);
     int s = 0;
     if (pre) {   // binary node: x = relu(proj([src0; src1]) + bias_pre), kept in slot `res`
-        conv_kloop<1>(halo, xaddr, wbase, wstep, 8, s, wr, acc, false);
+        // (cleared registers here, not the zero-first form: with it the register allocator spills)
+#pragma unroll
+        for (int m = 0; m < MT; m++) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        conv_kloop<1, false>(halo, xaddr, wbase, wstep, 8, s, wr, acc, false);
         __syncthreads();
         halo_stage(halo, arena + (int64_t)t.src1 * slot_b, 256, tid, false);
         __syncthreads();
-        conv_kloop<1>(halo, xaddr, wbase, wstep, 8, s, wr, acc, false);
+        conv_kloop<1, false>(halo, xaddr, wbase, wstep, 8, s, wr, acc, false);
         wbase = (const char*)p.w_first + w33;
         load_wring(wr, wbase, wstep);
         acc_to_image(halo, acc, has_bias ? p.bias_pre + (int64_t)t.wgroup * 128 : nullptr, relu, nullptr,
                      arena + (int64_t)t.res * slot_b, tid);
         s = 0;
     }
-    conv_kloop<9>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+    STAMP(2);
+    conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+    STAMP(3);
 
     // intermediate map -> the image the second convolution reads; its weight stream starts now and
     // lands under the epilogue
@@ -383,13 +373,16 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     acc_to_image(halo, acc, has_bias ? p.bias_first + (int64_t)t.wgroup * 128 : nullptr, relu,
                  t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
     s = 0;
-    conv_kloop<9>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+    STAMP(4);
+    conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+    STAMP(5);
 
     const bool post = t.post_dst0 >= 0;
     char* d0 = arena + (int64_t)t.dst0 * slot_b;
     conv_epilogue(halo, acc, has_bias ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr, relu,
                   t.res >= 0 ? arena + (int64_t)t.res * slot_b : nullptr,
                   t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, d0, 128, tid);
+    STAMP(6);
     if (!post) return;
 
     // binary node, backward: the map just stored (dP) goes through the transposed 1x1 projection,
@@ -401,18 +394,15 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
         load_wring(wr, wbase, 2 * wstep);
         __syncthreads();     // the epilogue's stores are issued and its staging reads are done
         halo_stage(halo, d0, 256, tid, false);
-#pragma unroll
-        for (int m = 0; m < MT; m++) {
-            acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
         __syncthreads();
         s = 0;
-        conv_kloop<1>(halo, xaddr, wbase, 2 * wstep, 4, s, wr, acc, false);
+        conv_kloop<1, true>(halo, xaddr, wbase, 2 * wstep, 4, s, wr, acc, false);
         const int dslot = child ? t.post_dst1 : t.post_dst0, mslot = child ? t.post_mask1 : t.post_mask0;
         conv_epilogue(halo, acc, nullptr, false, nullptr, mslot >= 0 ? arena + (int64_t)mslot * slot_b : nullptr,
                       arena + (int64_t)dslot * slot_b, 128, tid);
     }
+    STAMP(7);
+#undef STAMP
 }
 
 extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stream) {

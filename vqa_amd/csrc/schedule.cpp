@@ -93,6 +93,55 @@ inline void push_tile(std::vector<int32_t>& b, int s0, int s1, int d0, int d1, i
 
 }  // namespace
 
+// Re-assign tree levels so that launches come in whole rounds of the device.
+//
+// The earliest-possible level of a node (1 + its deepest child) makes the first levels huge and the
+// last dozen tiny, and a level of n tiles costs about ceil(n / round) passes over the device
+// (round = 256 CUs x 2 resident workgroups): 538 tiles cost two passes, 20 tiles still cost a full
+// tile latency.  Only the deepest programs are critical, though; every other node has slack up to
+// its latest level (its parent's latest level - 1, the last level for a root).  List scheduling
+// over the same number of levels: each level takes every node that is due, then the ready nodes
+// with the least slack until it holds the even share of what is left, rounded up to whole rounds
+// (half a round once the share is that small).  Node ids, slots and results do not change; only
+// the launch a node runs in.
+static void balance_levels(vqa_plan* pl, int round) {
+    const int NV = (int)pl->nodes.size(), L = pl->num_levels;
+    if (L <= 1 || round <= 0) return;
+    std::vector<int> parent(NV, -1), pending(NV, 0), latest(NV, L - 1);
+    for (int v = 0; v < NV; v++) {
+        const PlanNode& nd = pl->nodes[v];
+        if (nd.child0 >= 0) { parent[nd.child0] = v; pending[v]++; }
+        if (nd.child1 >= 0) { parent[nd.child1] = v; pending[v]++; }
+    }
+    for (int v = NV - 1; v >= 0; v--)            // a parent's id is larger than its children's
+        if (parent[v] >= 0) latest[v] = latest[parent[v]] - 1;
+    // ready nodes bucketed by latest level; within a bucket first in, first out
+    std::vector<std::vector<int>> bucket(L);
+    std::vector<size_t> head(L, 0);
+    for (int v = 0; v < NV; v++) if (pending[v] == 0) bucket[latest[v]].push_back(v);
+    std::vector<int> take;
+    int done = 0, lowest = 0;
+    for (int t = 0; t < L; t++) {
+        const int remaining = NV - done, share = (remaining + (L - t) - 1) / (L - t);
+        const int target = share <= round / 2 ? round / 2 : (share + round - 1) / round * round;
+        take.clear();
+        while (lowest < L) {
+            if (head[lowest] == bucket[lowest].size()) { lowest++; continue; }
+            if (lowest > t && (int)take.size() >= target) break;
+            take.push_back(bucket[lowest][head[lowest]++]);
+        }
+        for (int v : take) {
+            pl->nodes[v].level = t;
+            const int p = parent[v];
+            if (p >= 0 && --pending[p] == 0) {
+                bucket[latest[p]].push_back(p);
+                lowest = std::min(lowest, latest[p]);
+            }
+        }
+        done += (int)take.size();
+    }
+}
+
 extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
                                   const int8_t* arity, int32_t V, int32_t null_id,
                                   int32_t start_id, int32_t scene_id, int32_t C,
@@ -132,6 +181,8 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
         maxlev = std::max(maxlev, nd.level);
     }
     pl->num_scene = ns; pl->num_unary = nu; pl->num_binary = nb; pl->num_levels = maxlev + 1;
+
+    if (flags & VQA_PLAN_BALANCE) balance_levels(pl, 512 / (C / 128));
 
     // arena slots
     pl->slot_F = 0; pl->slot_S0 = N; pl->slot_Y = 2 * N; pl->slot_H = 2 * N + NV;

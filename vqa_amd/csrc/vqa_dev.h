@@ -15,6 +15,42 @@ typedef __attribute__((ext_vector_type(4))) uint16_t u16x4;
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
+// Packed bf16-pair helpers.  Next to a workgroup that is busy in its MFMA loop a wave gets roughly
+// one vector instruction per MFMA slot, so epilogues are priced in instructions: these work on two
+// channels per instruction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2n __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// (a, b) -> packed bf16 pair, round to nearest even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t cvt_pk_bf16(f32x2 v) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2n));
+}
+// ReLU of a packed pair: as signed 16-bit integers a bf16 is negative iff its sign bit is set,
+// and max(., 0) also turns -0 into +0
+__device__ __forceinline__ uint32_t relu_pk_bf16(uint32_t v) {
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+// v * (m > 0) per bf16 of a packed pair
+__device__ __forceinline__ uint32_t mask_pk_bf16(uint32_t v, uint32_t m) {
+    const s16x2 one = {1, 1}, z = {0, 0};
+    const s16x2 k = __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(s16x2, m), one), z);
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v) * __builtin_bit_cast(u16x2, k));
+}
+// the two bf16 of a dword as floats
+__device__ __forceinline__ f32x2 unpack_pk_bf16(uint32_t v) {
+    return (f32x2){__uint_as_float(v << 16), __uint_as_float(v & 0xFFFF0000u)};
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter, which parks every wave until its global loads and stores have completed; where the
+// barrier separates LDS phases and the global accesses in flight are prefetches or final stores,
+// that wait is pure loss (a microsecond or more per barrier with a busy neighbour on the CU).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // D = A(16 x 32) * B(32 x 16) + C.  Lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15] (j<8)
 // and D[4*(l>>4)+r][l&15] (r<4).
 __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {

@@ -212,6 +212,8 @@ class ModuleNet(nn.Module):
         # module width 128: both convolutions of a residual body run in one kernel; False selects
         # the two-launch path (bit-identical results)
         self.fuse_residual_body = True
+        # run nodes that have slack in later tree levels so that launches fill whole rounds of the device
+        self.balance_levels = True
         self.grad_ready_hook = None   # set by the data-parallel wrapper: called as (name, grad tensor)
         self.backward_done_hook = None
         self.last_token_counts = None
@@ -409,7 +411,8 @@ class ModuleNet(nn.Module):
                 arrived.synchronize()
             fused = c == 128 and self.fuse_residual_body
             plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk,
-                        _lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED)
+                        (_lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED) |
+                        (_lib.PLAN_BALANCE if self.balance_levels else 0))
             st['plan'] = plan
             info = plan.info
             self.last_token_counts = plan.token_counts()

@@ -48,7 +48,8 @@ def conv_tiles(src, dst, w_packed, tiles, num_tiles, *, taps, k_chunks, n_out, s
 
 
 def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=None, bias_second=None,
-                   relu=False, tiles_offset=0, w_pre=None, bias_pre=None, w_post=None, num_pre=0, num_post=0):
+                   relu=False, tiles_offset=0, w_pre=None, bias_pre=None, w_post=None, num_pre=0, num_post=0,
+                   phase_stamps=None):
     """Every convolution of a 128-wide tree node, one workgroup per tile (vqa_resblock_tiles);
     `arena` is bf16 [slots][196][128], `tiles` holds 12-word vqa_resblock_tile records."""
     _need_cuda(arena, w_first, w_second, tiles)
@@ -63,6 +64,7 @@ def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=Non
     p.slot_stride, p.w_group_stride, p.w_pre_group_stride = 196 * 128, 9 * 128 * 128, 2 * 128 * 128
     p.flags = (_lib.CONV_BIAS if bias_first is not None else 0) | (_lib.CONV_RELU if relu else 0)
     p.num_tiles, p.num_pre, p.num_post = num_tiles, num_pre, num_post
+    p.phase_stamps = phase_stamps.data_ptr() if phase_stamps is not None else 0
     _lib.check(_lib.load().vqa_resblock_tiles(C.byref(p), _stream()))
 
 
