@@ -130,9 +130,10 @@ __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[
 // halo image is dead by now) and come back pixel-major: every global access is 16 bytes per lane,
 // 1 KiB contiguous per wave, and bias, residual, rounding, ReLU and mask are applied there, two
 // channels per instruction.   out = [relu]( acc + bias + res ) * (mask > 0)
-__device__ __forceinline__ void conv_epilogue(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
-                                              const char* rsrc, const char* msrc, char* dptr, int pix_stride,
-                                              int tid) {
+template <bool RES, bool MASK>
+__device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+                                                const char* rsrc, const char* msrc, char* dptr, int pix_stride,
+                                                int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     const int pc = tid & 15;            // this thread's 16-byte column of every row: channels 8*pc..8*pc+7
     f32x2 bv[4];
@@ -147,8 +148,8 @@ __device__ __forceinline__ void conv_epilogue(char* halo, const f32x4 (&acc)[MT]
         for (int i = 0; i < 7; i++) {
             const int pl = min((tid >> 4) + 16 * i, 97);
             const int64_t goff = ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2;
-            if (rsrc) rv[i] = *(const uint4*)(rsrc + goff);
-            if (msrc) mv[i] = *(const uint4*)(msrc + goff);
+            if (RES) rv[i] = *(const uint4*)(rsrc + goff);
+            if (MASK) mv[i] = *(const uint4*)(msrc + goff);
         }
         lds_barrier();       // K loop reads (half 0) / previous half's staging reads are done
         if (l15 < 14) {
@@ -167,20 +168,34 @@ __device__ __forceinline__ void conv_epilogue(char* halo, const f32x4 (&acc)[MT]
                 const f32x4 f0 = *(const f32x4*)(stg + pl * 132 + pc * 8);
                 const f32x4 f1 = *(const f32x4*)(stg + pl * 132 + pc * 8 + 4);
                 f32x2 o[4] = {{f0[0], f0[1]}, {f0[2], f0[3]}, {f1[0], f1[1]}, {f1[2], f1[3]}};
-                const uint32_t r[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
-                const uint32_t k[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
-                uint32_t w[4];
+                uint32_t r[4] = {0, 0, 0, 0}, k[4] = {0, 0, 0, 0}, w[4];
+                if (RES) { r[0] = rv[i].x; r[1] = rv[i].y; r[2] = rv[i].z; r[3] = rv[i].w; }
+                if (MASK) { k[0] = mv[i].x; k[1] = mv[i].y; k[2] = mv[i].z; k[3] = mv[i].w; }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     o[j] += bv[j];
-                    if (rsrc) o[j] += unpack_pk_bf16(r[j]);
+                    if (RES) o[j] += unpack_pk_bf16(r[j]);
                     w[j] = cvt_pk_bf16(o[j]);
                     if (relu) w[j] = relu_pk_bf16(w[j]);
-                    if (msrc) w[j] = mask_pk_bf16(w[j], k[j]);
+                    if (MASK) w[j] = mask_pk_bf16(w[j], k[j]);
                 }
                 *(uint4*)(dptr + ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2) = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
+    }
+}
+
+// one specialisation per combination: a residual or mask array that only some paths fill makes the
+// compiler carry placeholders for the others through the whole kernel (scalar-register spills)
+__device__ __forceinline__ void conv_epilogue(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+                                              const char* rsrc, const char* msrc, char* dptr, int pix_stride,
+                                              int tid) {
+    if (rsrc) {
+        if (msrc) conv_epilogue_t<true, true>(halo, acc, bias, relu, rsrc, msrc, dptr, pix_stride, tid);
+        else conv_epilogue_t<true, false>(halo, acc, bias, relu, rsrc, msrc, dptr, pix_stride, tid);
+    } else {
+        if (msrc) conv_epilogue_t<false, true>(halo, acc, bias, relu, rsrc, msrc, dptr, pix_stride, tid);
+        else conv_epilogue_t<false, false>(halo, acc, bias, relu, rsrc, msrc, dptr, pix_stride, tid);
     }
 }
 
@@ -261,11 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 
 // accumulators (+ bias, ReLU) -> bf16 -> interior of the halo image; then a row-wise pass applies
 // an optional mask, rewrites the image and stores the map to `dst` in 16-byte pieces.
-__device__ __forceinline__ void acc_to_image(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
-                                             const char* mask, char* dst, int tid) {
+template <bool MASK>
+__device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+                                               const char* mask, char* dst, int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     uint4 mv[13];
-    if (mask) {
+    if (MASK) {
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int e = tid + 256 * i, pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
@@ -297,7 +313,7 @@ __device__ __forceinline__ void acc_to_image(char* halo, const f32x4 (&acc)[MT][
             const int y = pix / 14, x = pix - y * 14;
             uint4* cell = (uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16);
             uint4 v = *cell;
-            if (mask) {
+            if (MASK) {
                 v = make_uint4(mask_pk_bf16(v.x, mv[i].x), mask_pk_bf16(v.y, mv[i].y), mask_pk_bf16(v.z, mv[i].z),
                                mask_pk_bf16(v.w, mv[i].w));
                 *cell = v;
@@ -306,6 +322,12 @@ __device__ __forceinline__ void acc_to_image(char* halo, const f32x4 (&acc)[MT][
         }
     }
     lds_barrier();
+}
+
+__device__ __forceinline__ void acc_to_image(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+                                             const char* mask, char* dst, int tid) {
+    if (mask) acc_to_image_t<true>(halo, acc, bias, relu, mask, dst, tid);
+    else acc_to_image_t<false>(halo, acc, bias, relu, mask, dst, tid);
 }
 
 __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase, int64_t wstep) {

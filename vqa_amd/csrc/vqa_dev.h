@@ -32,11 +32,16 @@ __device__ __forceinline__ uint32_t relu_pk_bf16(uint32_t v) {
     const s16x2 z = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
 }
-// v * (m > 0) per bf16 of a packed pair
+// v * (m > 0) per bf16 of a packed pair, as a bit mask: max(m, 0) clears negatives and -0, then
+// (0 - m) >> 15 (arithmetic) is all ones exactly where m was positive.  Inline asm because the
+// compiler rewrites any C form of this into per-half compares, selects and a permute.
 __device__ __forceinline__ uint32_t mask_pk_bf16(uint32_t v, uint32_t m) {
-    const s16x2 one = {1, 1}, z = {0, 0};
-    const s16x2 k = __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(s16x2, m), one), z);
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v) * __builtin_bit_cast(u16x2, k));
+    uint32_t k;
+    asm("v_pk_max_i16 %0, %1, 0\n\t"
+        "v_pk_sub_i16 %0, 0, %0\n\t"
+        "v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]"
+        : "=&v"(k) : "v"(m));
+    return v & k;
 }
 // the two bf16 of a dword as floats
 __device__ __forceinline__ f32x2 unpack_pk_bf16(uint32_t v) {
