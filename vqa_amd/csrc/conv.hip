@@ -45,26 +45,24 @@ __device__ __forceinline__ void halo_zero_border(char* halo, int tid) {
 }
 
 // copy one 128-channel chunk of a source map (196 pixels x 256 B) into the halo image interior,
-// through registers, BATCH 16-byte pieces per thread at a time (all 13 in flight at once where the
-// accumulators are not live yet, 7 where they are)
-template <int BATCH = 7>
+// through registers, 7 image rows at a time; thread = (image column x = tid >> 4, 16-byte piece
+// pc = tid & 15), so addresses step by constants from row to row
 __device__ __forceinline__ void halo_stage(char* halo, const char* sp, int pix_stride_bytes, int tid, bool diag_noload) {
+    const int x = tid >> 4, pc = tid & 15;
+    const bool active = x < 14;
+    const char* g = sp + (int64_t)(active ? x : 0) * pix_stride_bytes + pc * 16;
+    char* cell = halo + (16 + x + 1) * HALO_STRIDE + pc * 16;
 #pragma unroll 1
-    for (int i0 = 0; i0 < 13; i0 += BATCH) {
-        uint4 v[BATCH];
+    for (int y0 = 0; y0 < 14; y0 += 7) {
+        uint4 v[7];
 #pragma unroll
-        for (int i = 0; i < BATCH; i++) {
-            const int e = tid + 256 * (i0 + i), pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
-            if (diag_noload) v[i] = make_uint4(e, pix, pc, 0);
-            else v[i] = *(const uint4*)(sp + (int64_t)pix * pix_stride_bytes + pc * 16);
+        for (int i = 0; i < 7; i++) {
+            if (diag_noload) v[i] = make_uint4(x, pc, i, 0);
+            else v[i] = *(const uint4*)(g + (int64_t)(y0 + i) * 14 * pix_stride_bytes);
         }
+        if (active) {
 #pragma unroll
-        for (int i = 0; i < BATCH; i++) {
-            const int e = tid + 256 * (i0 + i), pix = e >> 4, pc = e & 15;
-            if (pix < VQA_HW) {
-                const int y = pix / 14, x = pix - y * 14;
-                *(uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16) = v[i];
-            }
+            for (int i = 0; i < 7; i++) *(uint4*)(cell + (y0 + i) * 16 * HALO_STRIDE) = v[i];
         }
     }
 }
@@ -140,33 +138,35 @@ __device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[M
 #pragma unroll
     for (int j = 0; j < 4; j++) bv[j] = bias ? *(const f32x2*)(bias + pc * 8 + 2 * j) : (f32x2){0.f, 0.f};
     float* stg = (float*)halo;          // [98 pixels][132 floats]: 528-byte rows keep the writes conflict-free
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-        // this thread's 16-byte pieces of the half: piece e -> pixel 98*half + (e >> 4)
+    // (a generic lambda called with a constant: a run-time `half` would select between accumulator
+    // registers with one v_cndmask per value)
+    auto do_half = [&](auto half_tag) {
+        constexpr int half = decltype(half_tag)::value;
+        // this thread's 16-byte pieces of the half: piece i -> pixel 98*half + (tid >> 4) + 16*i
+        const int64_t g0 = ((int64_t)(98 * half + (tid >> 4)) * pix_stride + pc * 8) * 2;
         uint4 rv[7], mv[7];
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            const int pl = min((tid >> 4) + 16 * i, 97);
-            const int64_t goff = ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2;
+            const int64_t goff = g0 + (i < 6 || (tid >> 4) < 2 ? (int64_t)i * 16 * pix_stride * 2 : 0);
             if (RES) rv[i] = *(const uint4*)(rsrc + goff);
             if (MASK) mv[i] = *(const uint4*)(msrc + goff);
         }
         lds_barrier();       // K loop reads (half 0) / previous half's staging reads are done
         if (l15 < 14) {
+            float* row = stg + l15 * 132 + wave * 32 + lq * 4;
 #pragma unroll
             for (int mm = 0; mm < 7; mm++) {
-                float* row = stg + (mm * 14 + l15) * 132 + wave * 32 + lq * 4;
-                *(f32x4*)(row) = half ? acc[7 + mm][0] : acc[mm][0];
-                *(f32x4*)(row + 16) = half ? acc[7 + mm][1] : acc[mm][1];
+                *(f32x4*)(row + mm * 14 * 132) = acc[7 * half + mm][0];
+                *(f32x4*)(row + mm * 14 * 132 + 16) = acc[7 * half + mm][1];
             }
         }
         lds_barrier();
+        const float* src = stg + (tid >> 4) * 132 + pc * 8;
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            const int pl = (tid >> 4) + 16 * i;
-            if (pl < 98) {
-                const f32x4 f0 = *(const f32x4*)(stg + pl * 132 + pc * 8);
-                const f32x4 f1 = *(const f32x4*)(stg + pl * 132 + pc * 8 + 4);
+            if (i < 6 || (tid >> 4) < 2) {       // pixel (tid >> 4) + 16 i < 98
+                const f32x4 f0 = *(const f32x4*)(src + i * 16 * 132);
+                const f32x4 f1 = *(const f32x4*)(src + i * 16 * 132 + 4);
                 f32x2 o[4] = {{f0[0], f0[1]}, {f0[2], f0[3]}, {f1[0], f1[1]}, {f1[2], f1[3]}};
                 uint32_t r[4] = {0, 0, 0, 0}, k[4] = {0, 0, 0, 0}, w[4];
                 if (RES) { r[0] = rv[i].x; r[1] = rv[i].y; r[2] = rv[i].z; r[3] = rv[i].w; }
@@ -179,10 +179,12 @@ __device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[M
                     if (relu) w[j] = relu_pk_bf16(w[j]);
                     if (MASK) w[j] = mask_pk_bf16(w[j], k[j]);
                 }
-                *(uint4*)(dptr + ((int64_t)(98 * half + pl) * pix_stride + pc * 8) * 2) = make_uint4(w[0], w[1], w[2], w[3]);
+                *(uint4*)(dptr + g0 + (int64_t)i * 16 * pix_stride * 2) = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
-    }
+    };
+    do_half(std::integral_constant<int, 0>{});
+    do_half(std::integral_constant<int, 1>{});
 }
 
 // one specialisation per combination: a residual or mask array that only some paths fill makes the
@@ -280,13 +282,16 @@ template <bool MASK>
 __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
                                                const char* mask, char* dst, int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-    uint4 mv[13];
+    // row pass mapping: thread = (image column x = tid >> 4, 16-byte piece pc = tid & 15), looping over
+    // the 14 image rows: every address is a constant step per row (no per-piece index arithmetic),
+    // a wave still covers 4 pixels x 256 B = 1 KiB contiguous per access; columns 14, 15 idle
+    const int x = tid >> 4, pc = tid & 15;
+    const bool active = x < 14;
+    const int goff = (active ? x : 0) * 256 + pc * 16;
+    uint4 mv[14];
     if (MASK) {
 #pragma unroll
-        for (int i = 0; i < 13; i++) {
-            const int e = tid + 256 * i, pix = min(e >> 4, VQA_HW - 1), pc = e & 15;
-            mv[i] = *(const uint4*)(mask + pix * 256 + pc * 16);
-        }
+        for (int y = 0; y < 14; y++) mv[y] = *(const uint4*)(mask + goff + y * 14 * 256);
     }
     lds_barrier();          // every wave has finished reading the image
     if (l15 < 14) {
@@ -295,30 +300,29 @@ __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT
             const int ch = wave * 32 + n * 16 + lq * 4;
             const f32x2 b0 = bias ? *(const f32x2*)(bias + ch) : (f32x2){0.f, 0.f};
             const f32x2 b1 = bias ? *(const f32x2*)(bias + ch + 2) : (f32x2){0.f, 0.f};
+            char* cell = halo + (16 + l15 + 1) * HALO_STRIDE + ch * 2;
 #pragma unroll
             for (int m = 0; m < MT; m++) {
                 uint2 pk;
                 pk.x = cvt_pk_bf16((f32x2){acc[m][n][0], acc[m][n][1]} + b0);
                 pk.y = cvt_pk_bf16((f32x2){acc[m][n][2], acc[m][n][3]} + b1);
                 if (relu) { pk.x = relu_pk_bf16(pk.x); pk.y = relu_pk_bf16(pk.y); }
-                *(uint2*)(halo + ((m + 1) * 16 + l15 + 1) * HALO_STRIDE + ch * 2) = pk;
+                *(uint2*)(cell + m * 16 * HALO_STRIDE) = pk;
             }
         }
     }
     lds_barrier();
+    if (active) {
+        char* cell = halo + (16 + x + 1) * HALO_STRIDE + pc * 16;
 #pragma unroll
-    for (int i = 0; i < 13; i++) {
-        const int e = tid + 256 * i, pix = e >> 4, pc = e & 15;
-        if (pix < VQA_HW) {
-            const int y = pix / 14, x = pix - y * 14;
-            uint4* cell = (uint4*)(halo + ((y + 1) * 16 + x + 1) * HALO_STRIDE + pc * 16);
-            uint4 v = *cell;
+        for (int y = 0; y < 14; y++) {
+            uint4 v = *(uint4*)(cell + y * 16 * HALO_STRIDE);
             if (MASK) {
-                v = make_uint4(mask_pk_bf16(v.x, mv[i].x), mask_pk_bf16(v.y, mv[i].y), mask_pk_bf16(v.z, mv[i].z),
-                               mask_pk_bf16(v.w, mv[i].w));
-                *cell = v;
+                v = make_uint4(mask_pk_bf16(v.x, mv[y].x), mask_pk_bf16(v.y, mv[y].y), mask_pk_bf16(v.z, mv[y].z),
+                               mask_pk_bf16(v.w, mv[y].w));
+                *(uint4*)(cell + y * 16 * HALO_STRIDE) = v;
             }
-            *(uint4*)(dst + pix * 256 + pc * 16) = v;
+            *(uint4*)(dst + goff + y * 14 * 256) = v;
         }
     }
     lds_barrier();
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
 #pragma unroll
     for (int m = 0; m < MT; m++) xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
 
-    halo_stage<7>(halo, arena + (int64_t)t.src0 * slot_b, 256, tid, false);
+    halo_stage(halo, arena + (int64_t)t.src0 * slot_b, 256, tid, false);
     __syncthreads();
     STAMP(1);
     int s = 0;
