@@ -195,6 +195,12 @@ typedef struct {
 
 int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);
 
+/* fp32 variants (v_mfma_f32_16x16x4_f32, fp32 maps): same descriptors and epilogue semantics.
+ * Weights are not packed: `w` is fp32 [group][tap][k][n] (n contiguous, k over all source chunks in
+ * order), w_group_stride = taps * K * n_out.  The input gradient uses the flipped, transposed array.
+ * vqa_wgrad_tiles_f32 always accumulates atomically into dw [group][tap][k][n]. */
+int vqa_conv_tiles_f32(const vqa_conv_params* p, int32_t taps, void* stream);
+
 /* Weight packing: fp32 tensor -> bf16 image the conv kernel DMA-copies into LDS.
  * Source element (n, k, t) is at w[group*g_stride + n*n_stride + k*k_stride + (flip ? taps-1-t : t)]
  * (forward: n = out channel, k = in channel; input-gradient: swapped and flipped). */
@@ -240,6 +246,7 @@ typedef struct {
 } vqa_wgrad_params;
 
 int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* stream);
+int vqa_wgrad_tiles_f32(const vqa_wgrad_params* p, int32_t taps, void* stream);
 
 /* out[group][n][k][tap] (torch's OIHW, groups apart by out_g_stride) = sum of the partial blocks
  * of the group's items; a group without items gets zeros.  items / num_items / n_out / k_chunks as
@@ -299,6 +306,9 @@ int vqa_col_sum(const void* x, float* out, int32_t rows, int32_t cols, int64_t l
 int vqa_slot_sum_mask(void* arena, const int32_t* offsets, const int32_t* src_slots,
                       const int32_t* dst_slots, const int32_t* mask_slots, int32_t n_dst,
                       int64_t slot_elems, void* stream);
+int vqa_slot_sum_mask_f32(float* arena, const int32_t* offsets, const int32_t* src_slots,
+                          const int32_t* dst_slots, const int32_t* mask_slots, int32_t n_dst,
+                          int64_t slot_elems, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing for the benchmark (no counterpart in the reference).  Every launch of an MFMA
@@ -334,6 +344,11 @@ typedef struct {
 /* vqa_tree_ctx.flags: run the residual body as two vqa_conv_tiles launches even where the fused
  * vqa_resblock_tiles kernel applies (C == 128); same results, for comparison and timing. */
 #define VQA_TREE_UNFUSED 1
+/* fp32 maps and weights (the tolerance configuration): the arena holds fp32 [slots][196][C], the
+ * weight pointers are plain fp32 [V][tap][k][n] arrays (see vqa_conv_tiles_f32), the separate tile
+ * lists are used, and g_conv1 / g_conv2 / g_proj are fp32 accumulators [V][tap][k][n] that the
+ * caller zeroes first and converts with vqa_unpack_conv_grad (wgrad_partial is not used). */
+#define VQA_TREE_F32 2
 
 int vqa_tree_forward(const vqa_plan* plan, const vqa_tree_ctx* ctx, void* stream);
 /* input gradients level by level, scene fan-in, then all weight gradients */

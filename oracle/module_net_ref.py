@@ -97,14 +97,17 @@ class _Force(torch.autograd.Function):
     compared without the ReLU-mask flips that two independently rounded forwards always have."""
 
     @staticmethod
-    def forward(ctx, z, forced):
+    def forward(ctx, z, forced, round_grad=True):
         ctx.save_for_backward(forced > 0)
+        ctx.round_grad = round_grad
         return forced.to(z.dtype).clone()
 
     @staticmethod
     def backward(ctx, g):
         (mask,) = ctx.saved_tensors
-        return g.to(torch.bfloat16).to(torch.float32) * mask, None
+        if ctx.round_grad:
+            g = g.to(torch.bfloat16).to(torch.float32)
+        return g * mask, None, None
 
 
 class _RoundWeight(torch.autograd.Function):
@@ -151,9 +154,9 @@ class ModuleNetRef:
     def __init__(self, vocab, state_dict, dtype=torch.float32, storage='fp32', forced=None):
         """forced: optional callable (kind, index) -> stored activation tensor, kinds 'S0', 'F',
         'C1', ('FC', layer) for whole-batch tensors and 'H', 'Y', 'P' per node (index = global
-        node id in execution order) / per binary node; requires storage='bf16'."""
+        node id in execution order) / per binary node.  With storage='fp32' the forced values only
+        pin the ReLU masks (no rounding of values or gradients)."""
         assert storage in ('fp32', 'bf16')
-        assert forced is None or storage == 'bf16'
         self.vocab = vocab
         self.bf16 = storage == 'bf16'
         self.forced = forced
@@ -169,7 +172,7 @@ class ModuleNetRef:
     def _act(self, z, kind, index=0):
         """relu, then the storage rounding (or the forced stored value)."""
         if self.forced is not None:
-            return _Force.apply(z, self.forced(kind, index))
+            return _Force.apply(z, self.forced(kind, index), self.bf16)
         return self.q(F.relu(z))
 
     # Layers.py:29-39 (no batch-norm, proj None) and Module_Model.py:43-53

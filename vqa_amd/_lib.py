@@ -68,7 +68,7 @@ SEC = {name: i for i, name in enumerate((
     'WG_PITEMS', 'WG_PSRC0', 'WG_PSRC1', 'WG_PDY', 'SAMPLE_ITEMS_FINE'))}
 
 CONV_BIAS, CONV_RELU = 1, 2
-TREE_UNFUSED = 1
+TREE_UNFUSED, TREE_F32 = 1, 2
 PLAN_SKIP_SEPARATE, PLAN_SKIP_FUSED, PLAN_BALANCE = 1, 2, 4
 
 # name -> (restype, argtypes); every symbol include/vqa_amd.h declares
@@ -89,6 +89,9 @@ SIGNATURES = {
     'vqa_plan_slot': (i32, [vp, i32, i32]),
     'vqa_conv_tiles': (i32, [C.POINTER(ConvParams), i32, vp]),
     'vqa_resblock_tiles': (i32, [C.POINTER(ResblockParams), vp]),
+    'vqa_conv_tiles_f32': (i32, [C.POINTER(ConvParams), i32, vp]),
+    'vqa_wgrad_tiles_f32': (i32, [C.POINTER(WgradParams), i32, vp]),
+    'vqa_slot_sum_mask_f32': (i32, [vp, vp, vp, vp, vp, i32, i64, vp]),
     'vqa_pack_conv_weight': (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp]),
     'vqa_wgrad_tiles': (i32, [C.POINTER(WgradParams), i32, vp]),
     'vqa_wgrad_reduce': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),

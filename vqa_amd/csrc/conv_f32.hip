@@ -1,0 +1,267 @@
+// fp32 variants of the grouped convolution, its weight gradient and the scene fan-in sum
+// (gfx950, v_mfma_f32_16x16x4_f32, fp32 storage).  They serve the tolerance configuration
+// (results within 1e-3 of the reference's fp32 arithmetic), not the throughput one: plain
+// structure, one 32-channel slice of the source in LDS at a time, weights read through L2.
+//
+// Same tile / item descriptors, slot arithmetic and epilogue semantics as the bf16 kernels
+// (conv.hip, wgrad.hip); the maps are fp32 [196][C] and the weights are plain fp32
+// [group][tap][k][n] arrays (n contiguous) instead of the packed bf16 fragments.
+//
+// Replaces, at fp32, the same reference calls: nn.Conv2d of Layers.py:33-36 and
+// Module_Model.py:38-40,47-50,59-62,72-75, their input gradients (flipped, transposed weights) and
+// their weight gradients summed over every use of a token's module (Train_model.py:313).
+#include "vqa_dev.h"
+#include "plan.h"
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+#define F32_IMG_POS 264
+#define F32_IMG_STRIDE 34                      // floats per position: 32 channels + 2 (bank spread)
+#define F32_IMG_BYTES (F32_IMG_POS * F32_IMG_STRIDE * 4)
+
+// ---------------------------------------------------------------------------------------------
+// convolution: one workgroup = one tile (14 x 14 map) x 64 output channels; wave w owns 16 of them.
+// MFMA A = pixels (16 of an image row: 14 real + 2 halo/padding columns) x 4 channels, read from the
+// LDS halo image; B = 4 channels x 16 outputs, one float per lane straight from the weight array.
+// ---------------------------------------------------------------------------------------------
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_tiles_f32_kernel(vqa_conv_params p) {
+    __shared__ __attribute__((aligned(16))) float img[F32_IMG_POS * F32_IMG_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const vqa_conv_tile t = p.tiles[blockIdx.x];
+    const int n0 = blockIdx.y * 64 + wave * 16;          // this wave's first output channel
+    const int K = p.k_chunks * 128;
+    const float* w = (const float*)p.w + (int64_t)t.wgroup * p.w_group_stride;
+
+    for (int i = tid; i < F32_IMG_POS * F32_IMG_STRIDE; i += 256) img[i] = 0.f;
+
+    f32x4v acc[14];
+#pragma unroll
+    for (int m = 0; m < 14; m++) acc[m] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < p.k_chunks * 4; c++) {           // 32-channel slices of the source
+        const int chunk = c >> 2;
+        int slot, choff;
+        if (p.pair_chunks > 0) { slot = (chunk / p.pair_chunks) ? t.src1 : t.src0; choff = (chunk % p.pair_chunks) * 128; }
+        else { slot = t.src0; choff = chunk * 128; }
+        choff += (c & 3) * 32;
+        const float* sp = (const float*)p.src + (int64_t)slot * p.src_slot_stride + choff;
+        __syncthreads();                                  // previous slice fully consumed / zero fill done
+        for (int e = tid; e < VQA_HW * 8; e += 256) {     // 8 float4 per pixel
+            const int pix = e >> 3, q = e & 7;
+            const int y = pix / 14, x = pix - y * 14;
+            const float4 v = *(const float4*)(sp + (int64_t)pix * p.src_pix_stride + q * 4);
+            float* d = img + ((y + 1) * 16 + x + 1) * F32_IMG_STRIDE + q * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        const int kbase = chunk * 128 + (c & 3) * 32;     // row of the weight array
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; tap++) {
+            const int tapoff = (TAPS == 9) ? ((tap / 3) * 16 + (tap % 3)) : 17;
+            const float* wt = w + ((int64_t)tap * K + kbase + lq) * p.n_out + n0 + l15;
+            const float* xb = img + (tapoff + l15) * F32_IMG_STRIDE + lq;
+#pragma unroll
+            for (int k4 = 0; k4 < 8; k4++) {
+                const float b = wt[(int64_t)k4 * 4 * p.n_out];
+#pragma unroll
+                for (int m = 0; m < 14; m++) {
+                    const float a = xb[m * 16 * F32_IMG_STRIDE + k4 * 4];
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: lane holds pixels (row m, columns 4*lq..4*lq+3) of output channel n0 + l15
+    const int ntile = blockIdx.y >> 1;                    // 128-channel block of this workgroup
+    int dslot, mslot, choff;
+    if (p.pair_out > 0) {
+        const int which = ntile / p.pair_out;
+        dslot = which ? t.dst1 : t.dst0;
+        mslot = which ? t.mask1 : t.mask0;
+        choff = (ntile % p.pair_out) * 128;
+    } else { dslot = t.dst0; mslot = t.mask0; choff = ntile * 128; }
+    if (dslot < 0) return;
+    const int ch = choff + (blockIdx.y & 1) * 64 + wave * 16 + l15;       // channel inside the destination map
+    const float bias = (p.flags & VQA_CONV_BIAS) ? p.bias[(int64_t)t.wgroup * p.n_out + n0 + l15] : 0.f;
+    float* dst = (float*)p.dst + (int64_t)dslot * p.dst_slot_stride + ch;
+    const float* res = t.res >= 0 ? (const float*)p.res + (int64_t)t.res * p.dst_slot_stride + ch : nullptr;
+    const float* msk = mslot >= 0 ? (const float*)p.mask + (int64_t)mslot * p.dst_slot_stride + ch : nullptr;
+#pragma unroll
+    for (int m = 0; m < 14; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int x = 4 * lq + r;
+            if (x < 14) {
+                const int64_t o = (int64_t)(m * 14 + x) * p.dst_pix_stride;
+                float v = acc[m][r] + bias;
+                if (res) v += res[o];
+                if (p.flags & VQA_CONV_RELU) v = fmaxf(v, 0.f);
+                if (msk) v = msk[o] > 0.f ? v : 0.f;
+                dst[o] = v;
+            }
+        }
+}
+
+extern "C" int vqa_conv_tiles_f32(const vqa_conv_params* p, int32_t taps, void* stream) {
+    if (!p || !p->src || !p->dst || !p->w || !p->tiles || (taps != 9 && taps != 1) || p->k_chunks <= 0 ||
+        p->n_out <= 0 || p->n_out % 128 != 0 || p->num_tiles < 0 || p->src_pix_stride % 4 != 0 ||
+        ((p->flags & VQA_CONV_BIAS) && !p->bias)) {
+        vqa_set_error("vqa_conv_tiles_f32: bad argument");
+        return VQA_EINVAL;
+    }
+    if (p->num_tiles == 0) return VQA_OK;
+    dim3 grid(p->num_tiles, p->n_out / 64), block(256);
+    if (taps == 9) hipLaunchKernelGGL(conv_tiles_f32_kernel<9>, grid, block, 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(conv_tiles_f32_kernel<1>, grid, block, 0, (hipStream_t)stream, *p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_conv_tiles_f32: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: one workgroup = one work item x 64 output channels x 32 source channels;
+// wave w owns 16 output channels, all taps and both 16-channel halves of the source slice.
+// The contraction runs over pixels, 4 per MFMA: A = 16 source channels x 4 pixels (from the halo
+// image, shifted by the tap), B = 4 pixels x 16 output channels (from the dy tile, whose columns
+// 14, 15 are zero).  Accumulators leave as fp32 atomics into dw [group][tap][k][n].
+// ---------------------------------------------------------------------------------------------
+#define F32_WG_IMG_STRIDE 48                   // floats per position: 32 channels + 16
+#define F32_WG_DY_STRIDE 80                    // floats per position: 64 channels + 16
+#define F32_WG_IMG_FLOATS (F32_IMG_POS * F32_WG_IMG_STRIDE)
+#define F32_WG_DY_FLOATS (224 * F32_WG_DY_STRIDE)
+#define F32_WG_LDS ((F32_WG_IMG_FLOATS + F32_WG_DY_FLOATS) * 4)
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_tiles_f32_kernel(vqa_wgrad_params p) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    float* img = smf;
+    float* dyt = smf + F32_WG_IMG_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const vqa_wgrad_item it = p.items[blockIdx.x];
+    const int oslice = blockIdx.y, ks = blockIdx.z;       // 64 outputs; 32-channel slice of the source
+    const int chunk = ks >> 2;
+    int which = 0, choff = chunk * 128;
+    if (p.pair_chunks > 0) { which = chunk / p.pair_chunks; choff = (chunk % p.pair_chunks) * 128; }
+    choff += (ks & 3) * 32;
+    const int32_t* sslots = which ? p.src1_slots : p.src_slots;
+
+    for (int i = tid; i < F32_WG_IMG_FLOATS + F32_WG_DY_FLOATS; i += 256) smf[i] = 0.f;
+
+    f32x4v acc[TAPS][2];
+#pragma unroll
+    for (int t = 0; t < TAPS; t++) { acc[t][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+    float bsum = 0.f;                                     // threads 0..63: column sums of dy
+
+    for (int n = 0; n < it.count; n++) {
+        const float* sp = (const float*)p.src + (int64_t)sslots[it.first + n] * p.src_slot_stride + choff;
+        const float* dp = (const float*)p.dy + (int64_t)p.dy_slots[it.first + n] * p.dy_slot_stride + oslice * 64;
+        __syncthreads();
+        for (int e = tid; e < VQA_HW * 8; e += 256) {
+            const int pix = e >> 3, q = e & 7;
+            const int y = pix / 14, x = pix - y * 14;
+            const float4 v = *(const float4*)(sp + (int64_t)pix * p.src_pix_stride + q * 4);
+            *(float4*)(img + ((y + 1) * 16 + x + 1) * F32_WG_IMG_STRIDE + q * 4) = v;
+        }
+        for (int e = tid; e < VQA_HW * 16; e += 256) {
+            const int pix = e >> 4, q = e & 15;
+            const int y = pix / 14, x = pix - y * 14;
+            const float4 v = *(const float4*)(dp + (int64_t)pix * p.dy_pix_stride + q * 4);
+            *(float4*)(dyt + (y * 16 + x) * F32_WG_DY_STRIDE + q * 4) = v;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f;
+            for (int r = 0; r < 224; r++) s += dyt[r * F32_WG_DY_STRIDE + tid];
+            bsum += s;
+        }
+#pragma unroll 1
+        for (int y = 0; y < 14; y++)
+#pragma unroll 1
+            for (int xg = 0; xg < 4; xg++) {
+                // B: pixel (y, 4*xg + lq), output channel 16*wave + l15
+                const float b = dyt[(y * 16 + xg * 4 + lq) * F32_WG_DY_STRIDE + wave * 16 + l15];
+                // A: source pixel shifted by the tap, channel l15 (+16)
+                const float* xa = img + (y * 16 + xg * 4 + lq) * F32_WG_IMG_STRIDE + l15;
+#pragma unroll
+                for (int t = 0; t < TAPS; t++) {
+                    const int tapoff = (TAPS == 9) ? ((t / 3) * 16 + (t % 3)) : 17;
+                    const float a0 = xa[tapoff * F32_WG_IMG_STRIDE], a1 = xa[tapoff * F32_WG_IMG_STRIDE + 16];
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[t][1], 0, 0, 0);
+                }
+            }
+    }
+
+    // D[i][j]: i = source channel 4*lq + r (+16 for the second half), j = output channel l15
+    const int k_in = p.k_chunks * 128;
+    const int kbase = chunk * 128 + (ks & 3) * 32;
+    float* dw = p.dw + (int64_t)it.group * p.dw_group_stride;
+#pragma unroll
+    for (int t = 0; t < TAPS; t++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = kbase + h * 16 + lq * 4 + r;
+                const int oc = oslice * 64 + wave * 16 + l15;
+                atomicAdd(dw + ((int64_t)t * k_in + i) * p.n_out + oc, acc[t][h][r]);
+            }
+    if (p.db && ks == 0 && tid < 64) atomicAdd(p.db + (int64_t)it.group * p.n_out + oslice * 64 + tid, bsum);
+}
+
+extern "C" int vqa_wgrad_tiles_f32(const vqa_wgrad_params* p, int32_t taps, void* stream) {
+    if (!p || !p->src || !p->dy || !p->items || !p->src_slots || !p->dy_slots || !p->dw ||
+        (taps != 9 && taps != 1) || p->k_chunks <= 0 || p->n_out <= 0 || p->n_out % 64 != 0 ||
+        p->src_pix_stride % 4 != 0 || p->dy_pix_stride % 4 != 0 || p->num_items < 0 ||
+        (p->pair_chunks > 0 && !p->src1_slots)) {
+        vqa_set_error("vqa_wgrad_tiles_f32: bad argument");
+        return VQA_EINVAL;
+    }
+    if (p->num_items == 0) return VQA_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_tiles_f32_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, F32_WG_LDS);
+        (void)hipFuncSetAttribute((const void*)wgrad_tiles_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F32_WG_LDS);
+        attr_set = true;
+    }
+    dim3 grid(p->num_items, p->n_out / 64, p->k_chunks * 4), block(256);
+    if (taps == 9) hipLaunchKernelGGL(wgrad_tiles_f32_kernel<9>, grid, block, F32_WG_LDS, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(wgrad_tiles_f32_kernel<1>, grid, block, F32_WG_LDS, (hipStream_t)stream, *p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_wgrad_tiles_f32: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}
+
+// dst slot d <- (sum over src slots offsets[d]..offsets[d+1]) * (mask slot > 0), fp32 maps
+__global__ __launch_bounds__(256) void slot_sum_mask_f32_kernel(float* __restrict__ arena, const int32_t* __restrict__ offsets,
+                                                                const int32_t* __restrict__ src_slots,
+                                                                const int32_t* __restrict__ dst_slots,
+                                                                const int32_t* __restrict__ mask_slots, int64_t slot_elems) {
+    const int d = blockIdx.y;
+    const int beg = offsets[d], end = offsets[d + 1];
+    float* dst = arena + (int64_t)dst_slots[d] * slot_elems;
+    const float* mk = arena + (int64_t)mask_slots[d] * slot_elems;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < slot_elems; e += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = beg; k < end; k++) s += arena[(int64_t)src_slots[k] * slot_elems + e];
+        dst[e] = mk[e] > 0.f ? s : 0.f;
+    }
+}
+
+extern "C" int vqa_slot_sum_mask_f32(float* arena, const int32_t* offsets, const int32_t* src_slots,
+                                     const int32_t* dst_slots, const int32_t* mask_slots, int32_t n_dst,
+                                     int64_t slot_elems, void* stream) {
+    if (!arena || !offsets || !src_slots || !dst_slots || !mask_slots || n_dst <= 0 || slot_elems <= 0) {
+        vqa_set_error("vqa_slot_sum_mask_f32: bad argument");
+        return VQA_EINVAL;
+    }
+    hipLaunchKernelGGL(slot_sum_mask_f32_kernel, dim3(32, n_dst), dim3(256), 0, (hipStream_t)stream, arena, offsets,
+                       src_slots, dst_slots, mask_slots, slot_elems);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_slot_sum_mask_f32: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}

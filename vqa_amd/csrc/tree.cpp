@@ -19,6 +19,10 @@ vqa_conv_params base_conv(const vqa_plan* pl, const vqa_tree_ctx* c) {
     return p;
 }
 
+int conv(const vqa_tree_ctx* c, const vqa_conv_params* p, int taps, void* stream) {
+    return (c->flags & VQA_TREE_F32) ? vqa_conv_tiles_f32(p, taps, stream) : vqa_conv_tiles(p, taps, stream);
+}
+
 const vqa_conv_tile* tiles_at(const vqa_tree_ctx* c, int word_off) {
     return (const vqa_conv_tile*)(c->blob + word_off);
 }
@@ -33,7 +37,7 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
     }
     const int cc = pl->C / 128;
     const int64_t w33 = (int64_t)9 * pl->C * pl->C, w11 = (int64_t)2 * pl->C * pl->C;
-    const bool fused = pl->C == 128 && !(c->flags & VQA_TREE_UNFUSED);
+    const bool fused = pl->C == 128 && !(c->flags & (VQA_TREE_UNFUSED | VQA_TREE_F32));
     if (fused ? !pl->has_fused : !pl->has_separate) {
         vqa_set_error("vqa_tree_forward: the plan was built without the tile lists of this path");
         return VQA_EINVAL;
@@ -59,21 +63,21 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
             p.tiles = tiles_at(c, lv.off_proj); p.num_tiles = lv.bcount;
             p.k_chunks = 2 * cc; p.pair_chunks = cc;
             p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
-            if ((rc = vqa_conv_tiles(&p, 1, stream))) return rc;
+            if ((rc = conv(c, &p, 1, stream))) return rc;
         }
         {                      // H = relu(conv1(in) + b1)     Layers.py:33 / Module_Model.py:47
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->w_conv1; p.bias = c->b_conv1; p.w_group_stride = w33;
             p.tiles = tiles_at(c, lv.off_conv1); p.num_tiles = lv.count;
             p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
-            if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+            if ((rc = conv(c, &p, 9, stream))) return rc;
         }
         {                      // Y = relu(in + conv2(H) + b2) Layers.py:33-36
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->w_conv2; p.bias = c->b_conv2; p.w_group_stride = w33;
             p.tiles = tiles_at(c, lv.off_conv2); p.num_tiles = lv.count;
             p.flags = VQA_CONV_BIAS | VQA_CONV_RELU;
-            if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+            if ((rc = conv(c, &p, 9, stream))) return rc;
         }
     }
     return VQA_OK;
@@ -81,7 +85,7 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
 
 extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void* stream) {
     if (!pl || !c || !c->arena || !c->blob || !c->wd_conv1 || !c->wd_conv2 || !c->g_conv1 || !c->g_conv2 ||
-        !c->gb_conv1 || !c->gb_conv2 || !c->wgrad_partial || c->C != pl->C ||
+        !c->gb_conv1 || !c->gb_conv2 || (!c->wgrad_partial && !(c->flags & VQA_TREE_F32)) || c->C != pl->C ||
         (pl->num_binary > 0 && (!c->wd_proj || !c->g_proj || !c->gb_proj))) {
         vqa_set_error("vqa_tree_backward: bad argument");
         return VQA_EINVAL;
@@ -89,7 +93,7 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     const int cc = pl->C / 128;
     const int64_t w33 = (int64_t)9 * pl->C * pl->C, w11 = (int64_t)2 * pl->C * pl->C;
     const int64_t slot = (int64_t)VQA_HW * pl->C;
-    const bool fused = pl->C == 128 && !(c->flags & VQA_TREE_UNFUSED);
+    const bool fused = pl->C == 128 && !(c->flags & (VQA_TREE_UNFUSED | VQA_TREE_F32));
     if (fused ? !pl->has_fused : !pl->has_separate) {
         vqa_set_error("vqa_tree_backward: the plan was built without the tile lists of this path");
         return VQA_EINVAL;
@@ -111,26 +115,30 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->wd_conv2; p.w_group_stride = w33;
             p.tiles = tiles_at(c, lv.off_dgrad2); p.num_tiles = lv.count;
-            if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+            if ((rc = conv(c, &p, 9, stream))) return rc;
         }
         {   // d(in) = (dgrad_conv1(dH) + dZ) * (in > 0)
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->wd_conv1; p.w_group_stride = w33;
             p.tiles = tiles_at(c, lv.off_dgrad1); p.num_tiles = lv.count;
-            if ((rc = vqa_conv_tiles(&p, 9, stream))) return rc;
+            if ((rc = conv(c, &p, 9, stream))) return rc;
         }
         if (lv.bcount > 0) {   // [dx; dy] = dP * Wproj, each masked by its own child's output
             vqa_conv_params p = base_conv(pl, c);
             p.w = c->wd_proj; p.w_group_stride = w11;
             p.tiles = tiles_at(c, lv.off_dproj); p.num_tiles = lv.bcount;
             p.n_out = 2 * pl->C; p.pair_out = cc;
-            if ((rc = vqa_conv_tiles(&p, 1, stream))) return rc;
+            if ((rc = conv(c, &p, 1, stream))) return rc;
         }
     }
     // gradient of the stem output: sum over the scene nodes of each sample, times (F > 0)
-    rc = vqa_slot_sum_mask(c->arena, c->blob + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
-                           c->blob + pl->sec_off[VQA_SEC_SCENE_SRC], c->blob + pl->sec_off[VQA_SEC_SLOTS_DF],
-                           c->blob + pl->sec_off[VQA_SEC_SLOTS_F], pl->N, slot, stream);
+    const bool f32 = (c->flags & VQA_TREE_F32) != 0;
+    rc = f32 ? vqa_slot_sum_mask_f32((float*)c->arena, c->blob + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
+                                     c->blob + pl->sec_off[VQA_SEC_SCENE_SRC], c->blob + pl->sec_off[VQA_SEC_SLOTS_DF],
+                                     c->blob + pl->sec_off[VQA_SEC_SLOTS_F], pl->N, slot, stream)
+             : vqa_slot_sum_mask(c->arena, c->blob + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
+                                 c->blob + pl->sec_off[VQA_SEC_SCENE_SRC], c->blob + pl->sec_off[VQA_SEC_SLOTS_DF],
+                                 c->blob + pl->sec_off[VQA_SEC_SLOTS_F], pl->N, slot, stream);
     if (rc) return rc;
 
     // weight gradients of every module, grouped by token
@@ -143,6 +151,30 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     w.num_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
     w.total_nodes = (int)pl->nodes.size();
     w.k_chunks = cc;
+    if (f32) {     // atomic accumulation into [V][tap][k][n] arrays the caller zeroed
+        w.dw_group_stride = w33;
+        w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C1];
+        w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C1];
+        w.dw = c->g_conv1; w.db = c->gb_conv1;
+        if ((rc = vqa_wgrad_tiles_f32(&w, 9, stream))) return rc;
+        w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C2];
+        w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C2];
+        w.dw = c->g_conv2; w.db = c->gb_conv2;
+        if ((rc = vqa_wgrad_tiles_f32(&w, 9, stream))) return rc;
+        if (pl->sec_cnt[VQA_SEC_WG_PITEMS] > 0) {
+            w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_PITEMS]);
+            w.num_items = pl->sec_cnt[VQA_SEC_WG_PITEMS];
+            w.total_nodes = pl->num_binary;
+            w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_PSRC0];
+            w.src1_slots = c->blob + pl->sec_off[VQA_SEC_WG_PSRC1];
+            w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_PDY];
+            w.k_chunks = 2 * cc; w.pair_chunks = cc;
+            w.dw_group_stride = w11;
+            w.dw = c->g_proj; w.db = c->gb_proj;
+            if ((rc = vqa_wgrad_tiles_f32(&w, 1, stream))) return rc;
+        }
+        return VQA_OK;
+    }
     w.partial = c->wgrad_partial;
     w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C1];
     w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C1];

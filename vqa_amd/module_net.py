@@ -214,6 +214,10 @@ class ModuleNet(nn.Module):
         self.fuse_residual_body = True
         # run nodes that have slack in later tree levels so that launches fill whole rounds of the device
         self.balance_levels = True
+        # 'bf16': bf16 storage and MFMA operands, fp32 accumulation (the throughput path);
+        # 'fp32': fp32 storage and fp32 MFMA for every convolution, rocBLAS fp32 for the linear layers
+        # (the tolerance configuration: results within 1e-3 of the reference's fp32 arithmetic)
+        self.precision = 'bf16'
         self.grad_ready_hook = None   # set by the data-parallel wrapper: called as (name, grad tensor)
         self.backward_done_hook = None
         self.last_token_counts = None
@@ -359,6 +363,10 @@ class ModuleNet(nn.Module):
         N, c, p_, cpad = x.size(0), d['c'], d['p'], d['cin_pad']
         if x.dim() != 4 or tuple(x.shape[1:]) != (d['cin'], 14, 14):
             raise ValueError('features must be [N, %d, 14, 14]' % d['cin'])
+        if self.precision == 'fp32':
+            return self._run_forward_f32(x, program, need_grad)
+        if self.precision != 'bf16':
+            raise ValueError("precision must be 'bf16' or 'fp32'")
         T = program.size(1)
         ws = self._pool.acquire()
         st = _CallState(N=N, ws=ws)
@@ -483,6 +491,176 @@ class ModuleNet(nn.Module):
             self.last_state = st
         return st
 
+    # ------------------------------------------------------------------ fp32 path
+    def _weights_f32(self, dev):
+        """Plain fp32 [group][tap][k][n] weight arrays for the fp32 kernels, forward and
+        input-gradient (flipped taps, transposed) forms."""
+        d = self._dims
+        c, p_, cin, cpad = d['c'], d['p'], d['cin'], d['cin_pad']
+        nv = len(self._tokens)
+        with torch.no_grad():
+            def fwd(w):      # [..., o, i, 3, 3] -> [..., 9, i, o]
+                return w.permute(*range(w.dim() - 4), -2, -1, -3, -4).reshape(*w.shape[:-4], -1, w.shape[-3], w.shape[-4]).contiguous()
+
+            def bwd(w):      # [..., o, i, 3, 3] -> [..., 9 (flipped), o, i]
+                return w.flip(-2, -1).permute(*range(w.dim() - 4), -2, -1, -4, -3).reshape(*w.shape[:-4], -1, w.shape[-4], w.shape[-3]).contiguous()
+            w1 = torch.stack([self._modules[t].conv1.weight for t in self._tokens]).to(dev, torch.float32)
+            w2 = torch.stack([self._modules[t].conv2.weight for t in self._tokens]).to(dev, torch.float32)
+            wp = torch.zeros(nv, c, 2 * c, device=dev)
+            bp = torch.zeros(nv, c, device=dev)
+            for i, t in enumerate(self._tokens):
+                if self._binary[i]:
+                    wp[i] = self._modules[t].proj.weight.reshape(c, 2 * c)
+                    bp[i] = self._modules[t].proj.bias
+            s0w = torch.zeros(c, cpad, 3, 3, device=dev)
+            s0w[:, :cin] = self.stem[0].weight
+            cl = self.classifier[0].weight.reshape(p_, c)
+            return {
+                'w_conv1': fwd(w1), 'w_conv2': fwd(w2), 'wd_conv1': bwd(w1), 'wd_conv2': bwd(w2),
+                'w_proj': wp.permute(0, 2, 1).contiguous(), 'wd_proj': wp.contiguous(),
+                'b_conv1': torch.stack([self._modules[t].conv1.bias for t in self._tokens]).to(dev, torch.float32).contiguous(),
+                'b_conv2': torch.stack([self._modules[t].conv2.bias for t in self._tokens]).to(dev, torch.float32).contiguous(),
+                'b_proj': bp,
+                'w_stem0': fwd(s0w), 'w_stem1': fwd(self.stem[2].weight.detach()), 'wd_stem1': bwd(self.stem[2].weight.detach()),
+                'w_cls': cl.t().contiguous(), 'wd_cls': cl.contiguous(),
+                'b_stem0': self.stem[0].bias.detach(), 'b_stem1': self.stem[2].bias.detach(),
+                'b_cls': self.classifier[0].bias.detach(),
+            }
+
+    def _run_forward_f32(self, x, program, need_grad):
+        d = self._dims
+        dev = x.device
+        N, c, p_, cin, cpad = x.size(0), d['c'], d['p'], d['cin'], d['cin_pad']
+        plan = Plan(program.detach().cpu().numpy(), self.vocab, c, self.wgrad_chunk, _lib.PLAN_SKIP_FUSED)
+        info = plan.info
+        self.used_fns = torch.from_numpy(plan.used_fns()).to(program.device)
+        self.last_token_counts = plan.token_counts()
+        st = _CallState(N=N, plan=plan, f32=True)
+        st['pk'] = pk = self._weights_f32(dev)
+        st['blob'] = blob = torch.from_numpy(plan.blob()).to(dev)
+        slots = info.slots_total if need_grad else info.slots_fwd
+        st['arena'] = arena = torch.empty(slots * HW * c, dtype=torch.float32, device=dev)
+        xn = torch.zeros(N, HW, cpad, dtype=torch.float32, device=dev)
+        xn[:, :, :cin] = x.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(N, HW, cin)
+        st['x_nhwc'] = xn
+        slot = (HW * c, c)
+        self._conv(st, xn, arena, pk['w_stem0'], 'STEM0_TILES', 9, cpad // 128, c, (HW * cpad, cpad), slot,
+                   bias=pk['b_stem0'], relu=True, f32=True)
+        self._conv(st, arena, arena, pk['w_stem1'], 'STEM1_TILES', 9, c // 128, c, slot, slot,
+                   bias=pk['b_stem1'], relu=True, f32=True)
+        tctx = self._tree_ctx(st, pk)
+        tctx.flags = _lib.TREE_F32
+        _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
+        st['c1'] = c1 = torch.empty(N, HW * p_, dtype=torch.float32, device=dev)
+        self._conv(st, arena, c1, pk['w_cls'], 'CLS_FWD_TILES', 1, c // 128, p_, slot, (HW * p_, p_),
+                   bias=pk['b_cls'], relu=True, f32=True)
+        # linear layers on rocBLAS fp32; the first one's weight re-ordered from the reference's
+        # flatten order c*196+hw (Layers.py:42-44) to the channels-last hw*P+c
+        acts, ws_ = [c1], []
+        fcs = list(d['fcs']) + [d['na']]
+        with torch.no_grad():
+            for li, fo in enumerate(fcs):
+                lin = self.classifier[self._fc_idx[li]]
+                w = lin.weight.detach()
+                if li == 0:
+                    w = w.view(fo, p_, HW).permute(0, 2, 1).reshape(fo, HW * p_).contiguous()
+                ws_.append(w)
+                y = torch.addmm(lin.bias.detach(), acts[-1], w.t())
+                if li < len(fcs) - 1:
+                    y = torch.relu_(y)
+                acts.append(y)
+        st['acts'], st['fc_w'] = acts[:-1], ws_
+        st['logits'] = acts[-1]
+        if self.keep_state:
+            self.last_state = st
+        return st
+
+    def _run_backward_f32(self, st, dlogits):
+        d = self._dims
+        plan, pk, N = st['plan'], st['pk'], st['N']
+        dev = dlogits.device
+        lib = _lib.load()
+        c, p_, cin, cpad, nv = d['c'], d['p'], d['cin'], d['cin_pad'], len(self._tokens)
+        arena, blob, acts, fc_w = st['arena'], st['blob'], st['acts'], st['fc_w']
+        slot = (HW * c, c)
+        fcs = list(d['fcs']) + [d['na']]
+        f32 = dict(dtype=torch.float32, device=dev)
+        grads = {}
+        g = dlogits.detach().to(torch.float32).contiguous()
+        for li in range(len(fcs) - 1, -1, -1):
+            name = 'classifier.%d' % self._fc_idx[li]
+            gw = g.t() @ acts[li]
+            if li == 0:
+                gw = gw.view(fcs[0], HW, p_).permute(0, 2, 1).reshape(fcs[0], p_ * HW).contiguous()
+            grads[name + '.weight'], grads[name + '.bias'] = gw, g.sum(0)
+            g = (g @ fc_w[li]) * (acts[li] > 0)
+        dc1 = g.contiguous()      # [N][196][P], already times (C1 > 0)
+
+        it_off, it_cnt = plan.section('SAMPLE_ITEMS')
+        sec = lambda n: (blob, plan.section(n)[0])
+        wg = dict(src_pix_stride=c, dy_pix_stride=c, src_slot_stride=HW * c, dy_slot_stride=HW * c, f32=True)
+        gcw, gcb = torch.zeros(1, 1, c, p_, **f32), torch.zeros(p_, **f32)
+        ops.wgrad_tiles(arena, dc1, (blob, it_off), it_cnt, sec('SLOTS_ROOTY'), sec('SLOTS_IDENT'), gcw, gcb,
+                        taps=1, k_chunks=c // 128, n_out=p_, dw_group_stride=c * p_, total_nodes=N,
+                        **dict(wg, dy_pix_stride=p_, dy_slot_stride=HW * p_))
+        gw = torch.empty(p_, c, 1, 1, **f32)
+        ops.unpack_conv_grad(gcw, gw, 1, p_, c, 1, 0)
+        grads['classifier.0.weight'], grads['classifier.0.bias'] = gw, gcb
+        self._conv(st, dc1, arena, pk['wd_cls'], 'CLS_DGRAD_TILES', 1, p_ // 128, c, (HW * p_, p_), slot,
+                   mask=arena, f32=True)
+
+        acc = {'g_conv1': torch.zeros(nv, 9, c, c, **f32), 'g_conv2': torch.zeros(nv, 9, c, c, **f32),
+               'g_proj': torch.zeros(nv, 2 * c, c, **f32), 'gb_conv1': torch.zeros(nv, c, **f32),
+               'gb_conv2': torch.zeros(nv, c, **f32), 'gb_proj': torch.zeros(nv, c, **f32)}
+        tctx = self._tree_ctx(st, pk, acc)
+        tctx.flags = _lib.TREE_F32
+        _lib.check(lib.vqa_tree_backward(plan.handle, C.byref(tctx), ops._stream()))
+        gw1 = torch.empty(nv, c, c, 3, 3, **f32)
+        gw2 = torch.empty(nv, c, c, 3, 3, **f32)
+        gwp = torch.empty(nv, c, 2 * c, 1, 1, **f32)
+        ops.unpack_conv_grad(acc['g_conv1'], gw1, nv, c, c, 9, c * c * 9)
+        ops.unpack_conv_grad(acc['g_conv2'], gw2, nv, c, c, 9, c * c * 9)
+        ops.unpack_conv_grad(acc['g_proj'], gwp, nv, c, 2 * c, 1, 2 * c * c)
+        counts = plan.token_counts()
+        for i, tok in enumerate(self._tokens):
+            if counts[i] == 0:
+                continue
+            if self._binary[i]:
+                grads[tok + '.proj.weight'], grads[tok + '.proj.bias'] = gwp[i], acc['gb_proj'][i]
+            grads[tok + '.conv1.weight'], grads[tok + '.conv1.bias'] = gw1[i], acc['gb_conv1'][i]
+            grads[tok + '.conv2.weight'], grads[tok + '.conv2.bias'] = gw2[i], acc['gb_conv2'][i]
+
+        self._conv(st, arena, arena, pk['wd_stem1'], 'STEM1_DGRAD_TILES', 9, c // 128, c, slot, slot, mask=arena, f32=True)
+        gs1, gs1b = torch.zeros(1, 9, c, c, **f32), torch.zeros(c, **f32)
+        ops.wgrad_tiles(arena, arena, (blob, it_off), it_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), gs1, gs1b,
+                        taps=9, k_chunks=c // 128, n_out=c, dw_group_stride=9 * c * c, total_nodes=N, **wg)
+        gs0, gs0b = torch.zeros(1, 9, cpad, c, **f32), torch.zeros(c, **f32)
+        ops.wgrad_tiles(st['x_nhwc'], arena, (blob, it_off), it_cnt, sec('SLOTS_IDENT'), sec('SLOTS_DS0'), gs0, gs0b,
+                        taps=9, k_chunks=cpad // 128, n_out=c, dw_group_stride=9 * cpad * c, total_nodes=N,
+                        **dict(wg, src_pix_stride=cpad, src_slot_stride=HW * cpad))
+        gw = torch.empty(c, c, 3, 3, **f32)
+        ops.unpack_conv_grad(gs1, gw, 1, c, c, 9, 0)
+        grads['stem.2.weight'], grads['stem.2.bias'] = gw, gs1b
+        gw = torch.empty(c, cpad, 3, 3, **f32)
+        ops.unpack_conv_grad(gs0, gw, 1, c, cpad, 9, 0)
+        grads['stem.0.weight'] = gw[:, :cin].contiguous() if cpad != cin else gw
+        grads['stem.0.bias'] = gs0b
+
+        out = []
+        for name, p in self._param_groups():
+            gr = grads.get(name)
+            if gr is not None:
+                gr = gr.reshape(p.shape)
+                if self.grad_ready_hook is not None:
+                    self.grad_ready_hook(name, gr)
+            out.append(gr if p.requires_grad else None)
+        self._packed_stale = True
+        if self.backward_done_hook is not None:
+            self.backward_done_hook()
+        if not self.keep_state:
+            st.release()
+        return out
+
     def stored_activation(self, st, kind, index=0):
         """A stored forward activation of call `st` as an fp32 CPU tensor in the reference's NCHW
         layout: kinds 'S0', 'F', 'C1', ('FC', layer) are whole-batch, 'H', 'Y' take a node id and
@@ -510,6 +688,8 @@ class ModuleNet(nn.Module):
 
     # ------------------------------------------------------------------ backward
     def _run_backward(self, st, dlogits):
+        if st.get('f32'):
+            return self._run_backward_f32(st, dlogits)
         d = self._dims
         plan, pk, N = st['plan'], st['pk'], st['N']
         dev = dlogits.device

@@ -29,8 +29,9 @@ def _need_cuda(*ts):
 
 def conv_tiles(src, dst, w_packed, tiles, num_tiles, *, taps, k_chunks, n_out, src_slot_stride,
                dst_slot_stride, src_pix_stride, dst_pix_stride, w_group_stride, bias=None,
-               res=None, mask=None, pair_chunks=0, pair_out=0, relu=False, tiles_offset=0):
-    """tiles: int32 device tensor holding vqa_conv_tile records from word `tiles_offset`."""
+               res=None, mask=None, pair_chunks=0, pair_out=0, relu=False, tiles_offset=0, f32=False):
+    """tiles: int32 device tensor holding vqa_conv_tile records from word `tiles_offset`.
+    f32: fp32 maps and plain fp32 [group][tap][k][n] weights (vqa_conv_tiles_f32)."""
     _need_cuda(src, dst, w_packed, tiles)
     p = _lib.ConvParams()
     p.src, p.dst = src.data_ptr(), dst.data_ptr()
@@ -44,7 +45,8 @@ def conv_tiles(src, dst, w_packed, tiles, num_tiles, *, taps, k_chunks, n_out, s
     p.k_chunks, p.n_out, p.pair_chunks, p.pair_out = k_chunks, n_out, pair_chunks, pair_out
     p.flags = (_lib.CONV_BIAS if bias is not None else 0) | (_lib.CONV_RELU if relu else 0)
     p.num_tiles = num_tiles
-    _lib.check(_lib.load().vqa_conv_tiles(C.byref(p), taps, _stream()))
+    fn = _lib.load().vqa_conv_tiles_f32 if f32 else _lib.load().vqa_conv_tiles
+    _lib.check(fn(C.byref(p), taps, _stream()))
 
 
 def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=None, bias_second=None,
@@ -82,7 +84,7 @@ def pack_conv_weight(w, groups, n_out, k_in, taps, g_stride, n_stride, k_stride,
 
 def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps, k_chunks, n_out,
                 src_slot_stride, dy_slot_stride, src_pix_stride, dy_pix_stride, dw_group_stride,
-                src1_slots=None, pair_chunks=0, total_nodes=0, partial=None):
+                src1_slots=None, pair_chunks=0, total_nodes=0, partial=None, f32=False):
     """items / *_slots are (tensor, word_offset) pairs into an int32 device blob.  With `partial`
     (fp32 workspace of num_items * n_out/64 * k_chunks * taps * 8192 elements) the workgroups store
     partial blocks for wgrad_reduce and `dw` may be None; otherwise they add into `dw` atomically."""
@@ -101,7 +103,8 @@ def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps,
     p.src_pix_stride, p.dy_pix_stride = src_pix_stride, dy_pix_stride
     p.k_chunks, p.pair_chunks, p.n_out, p.num_items = k_chunks, pair_chunks, n_out, num_items
     p.total_nodes = total_nodes
-    _lib.check(_lib.load().vqa_wgrad_tiles(C.byref(p), taps, _stream()))
+    fn = _lib.load().vqa_wgrad_tiles_f32 if f32 else _lib.load().vqa_wgrad_tiles
+    _lib.check(fn(C.byref(p), taps, _stream()))
 
 
 def wgrad_reduce(partial, items, num_items, groups, n_out, k_chunks, taps, out, out_g_stride):
