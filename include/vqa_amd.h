@@ -53,7 +53,8 @@ typedef struct {
     int32_t wgrad_items;    /* work items of the grouped weight-gradient launch */
     int32_t max_level_tiles;
     int32_t wgrad_partial_blocks; /* vqa_tree_backward's workspace, in blocks of 8192 floats */
-    int32_t reserved[2];
+    int32_t num_images;     /* N, or the image count of vqa_schedule_build_shared */
+    int32_t reserved[1];
 } vqa_plan_info;
 
 /* programs: host int64 [N][T].  arity: int8 [V] (0 scene, 1 unary, 2 binary), indexed by token id
@@ -72,6 +73,16 @@ typedef struct {
 int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T, const int8_t* arity,
                        int32_t V, int32_t null_id, int32_t start_id, int32_t scene_id, int32_t C,
                        int32_t wgrad_chunk, int32_t flags, vqa_plan** out);
+/* The same for samples that share images (candidate-program scoring, Train_model.py:339-347: one
+ * question's K programs run on K copies of one image).  image_of_sample: int32 [N], values in
+ * [0, num_images).  Nodes are interned per (image, token, inputs): a subtree that several programs
+ * of one image have in common is a single node, computed once; the stem runs once per image
+ * (F and S0 slots, the stem tile lists and the node table's `sample` field are per image).
+ * Forward only: vqa_tree_backward refuses such a plan. */
+int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int32_t T, const int8_t* arity,
+                              int32_t V, int32_t null_id, int32_t start_id, int32_t scene_id, int32_t C,
+                              int32_t wgrad_chunk, int32_t flags, const int32_t* image_of_sample,
+                              int32_t num_images, vqa_plan** out);
 void vqa_plan_free(vqa_plan* plan);
 int vqa_plan_get_info(const vqa_plan* plan, vqa_plan_info* out);
 /* used_fns as ModuleNet.used_fns (Module_Model.py:227,231): float [N][T] of 0/1 */

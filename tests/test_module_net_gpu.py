@@ -306,3 +306,39 @@ def test_width_256_deep_programs(vocab):
     x = synth.synth_features(31, 10, dims['feature_dim'])
     ans = synth.synth_answers(31, 10)
     check_pair(*run_pair(vocab, dims, prog, x, ans, 13))
+
+
+def test_score_candidates_shares_images_and_subtrees(vocab):
+    """Candidate scoring (Train_model.py:339-347): K programs per image.  score_candidates runs the
+    stem once per image and common subtrees once; its logits are the bits forward() gives on the
+    expanded batch, and an expand()-ed feature tensor passed to forward() takes the same path."""
+    from vqa_amd.module_net import ModuleNet
+    from vqa_amd.schedule import Plan
+    dims = small_dims(128)
+    sd = synth.synth_state_dict(41, vocab, **dims)
+    M, K, T = 3, 8, 14
+    base = synth.synth_programs(42, M * K, vocab, max_len=T, max_nodes=12)
+    base[1] = base[0]                                    # identical candidates
+    base[2, :3] = base[0, :3]                            # a different prefix: other subtrees may still coincide
+    prog = torch.from_numpy(base)
+    img = torch.arange(M).repeat_interleave(K)
+    x = torch.from_numpy(synth.synth_features(43, M, dims['feature_dim']))
+    net = ModuleNet(False, vocab, **dims)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    with torch.no_grad():
+        full = net(x[img].cuda(), prog.cuda())
+        shared = net.score_candidates(x.cuda(), prog.cuda(), img)
+        one = net(x[:1].cuda().expand(K, -1, -1, -1), prog[:K].cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(full, shared)
+    assert torch.equal(full[:K], one)
+    assert not shared.requires_grad
+    np.testing.assert_array_equal(net.used_fns.cpu().numpy()[:K], Plan(base[:K], vocab).used_fns())
+    # fewer nodes than the sum over programs: the K programs of an image share its scene node at least
+    assert Plan(base, vocab, image_index=img.numpy()).info.num_nodes < Plan(base, vocab).info.num_nodes
+    with torch.no_grad():
+        ref = ModuleNetRef(vocab, sd)(x[img], prog)
+    assert rel(shared, ref) <= TOL
+    with pytest.raises(IndexError):
+        net.score_candidates(x.cuda(), prog.cuda(), img + 1)

@@ -155,3 +155,37 @@ def test_balanced_levels_are_a_valid_schedule(vocab):
         toks = n1[ids, 1]
         assert (np.diff(toks) >= 0).all()               # still grouped by token inside a level
     np.testing.assert_array_equal(p0.used_fns(), p1.used_fns())
+
+
+def test_shared_image_plan_interns_common_subtrees(vocab):
+    """vqa_schedule_build_shared: programs of one image share nodes with equal (token, inputs);
+    used_fns stay per program; roots of identical programs coincide; programs of different images
+    share nothing."""
+    prog = synth.synth_programs(5, 12, vocab, max_len=14, max_nodes=10)
+    prog[1] = prog[0]
+    img = np.array([0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2])
+    p0, p1 = Plan(prog, vocab), Plan(prog, vocab, image_index=img)
+    np.testing.assert_array_equal(p0.used_fns(), p1.used_fns())
+    n1, r1 = p1.nodes(), p1.roots()
+    assert p1.info.num_images == 3 and p1.info.slots_total == p1.info.slots_fwd
+    assert r1[0] == r1[1]
+    assert len(n1) < len(p0.nodes())
+    # no two nodes describe the same computation; children precede parents; one scene node per image at most
+    keys = set()
+    scene = vocab['program_token_to_idx']['scene']
+    for v, (image, tok, _col, c0, c1, lvl) in enumerate(n1):
+        assert (image, tok, c0, c1) not in keys
+        keys.add((image, tok, c0, c1))
+        for c in (c0, c1):
+            if c >= 0:
+                assert c < v and n1[c, 0] == image and n1[c, 5] < lvl
+    assert sum(1 for r in n1 if r[1] == scene) <= 3
+    # expanding the shared plan per program gives back every program's own tree
+    n0, r0 = p0.nodes(), p0.roots()
+
+    def tree(nodes, v):
+        return (int(nodes[v, 1]),) + tuple(tree(nodes, c) for c in nodes[v, 3:5] if c >= 0)
+    for i in range(len(prog)):
+        assert tree(n0, r0[i]) == tree(n1, r1[i])
+    with pytest.raises(ValueError):
+        Plan(prog, vocab, image_index=img[:5])

@@ -17,8 +17,8 @@ class PlanInfo(C.Structure):
     _fields_ = [(n, i32) for n in ('N', 'T', 'C', 'num_nodes', 'num_scene', 'num_unary',
                                    'num_binary', 'num_levels', 'slots_fwd', 'slots_total',
                                    'blob_words', 'wgrad_items', 'max_level_tiles',
-                                   'wgrad_partial_blocks')] + \
-               [('reserved', i32 * 2)]
+                                   'wgrad_partial_blocks', 'num_images')] + \
+               [('reserved', i32 * 1)]
 
 
 class ConvParams(C.Structure):
@@ -77,6 +77,8 @@ SIGNATURES = {
     'vqa_last_error': (C.c_char_p, []),
     'vqa_schedule_build': (i32, [i64p, i32, i32, i8p, i32, i32, i32, i32, i32, i32, i32,
                                  C.POINTER(vp)]),
+    'vqa_schedule_build_shared': (i32, [i64p, i32, i32, i8p, i32, i32, i32, i32, i32, i32, i32, i32p, i32,
+                                        C.POINTER(vp)]),
     'vqa_plan_free': (None, [vp]),
     'vqa_plan_get_info': (i32, [vp, C.POINTER(PlanInfo)]),
     'vqa_plan_used_fns': (i32, [vp, f32p]),

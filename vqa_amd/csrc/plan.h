@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/vqa_amd.h"
@@ -16,6 +17,9 @@ struct PlanLevel {
 
 struct vqa_plan {
     int N = 0, T = 0, C = 0, V = 0;
+    int M = 0;                        // images: N, or fewer when samples share images (forward only)
+    bool shared = false;              // nodes interned per (image, token, inputs): PlanNode.sample is the image
+    std::unordered_map<uint64_t, int> interned;
     std::vector<PlanNode> nodes;      // execution order per sample, samples in order
     std::vector<PlanNode> pending;    // parse scratch
     std::vector<int32_t> roots;       // node id of each sample's root

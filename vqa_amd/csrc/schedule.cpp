@@ -26,9 +26,28 @@ namespace {
 
 struct Frame { int node; int need; };
 
+// A finished node becomes a row of the node table - or, when samples share images, the row that
+// already holds the same computation: same image, same token, same (already interned) inputs give
+// the same feature map, so it is computed once (common subtrees of the candidate programs of one
+// question, Train_model.py:339-347).
+int add_node(vqa_plan* pl, const PlanNode& nd) {
+    if (!pl->shared) {
+        pl->nodes.push_back(nd);
+        return (int)pl->nodes.size() - 1;
+    }
+    const uint64_t key = ((uint64_t)(uint32_t)nd.token << 56) | ((uint64_t)(uint32_t)nd.sample << 38) |
+                         ((uint64_t)(uint32_t)(nd.child0 + 1) << 19) | (uint64_t)(uint32_t)(nd.child1 + 1);
+    auto it = pl->interned.find(key);
+    if (it != pl->interned.end()) return it->second;
+    pl->nodes.push_back(nd);
+    const int id = (int)pl->nodes.size() - 1;
+    pl->interned.emplace(key, id);
+    return id;
+}
+
 // Iterative form of the recursive helper: a stack of open nodes waiting for inputs.
 int parse_row(const int64_t* row, int T, const int8_t* arity, int V, int null_id, int start_id,
-              int scene_id, int sample, vqa_plan* pl, float* used) {
+              int scene_id, int sample, int image, vqa_plan* pl, float* used) {
     std::vector<Frame> stack;
     int j = 0;
     const int base = (int)pl->nodes.size();
@@ -56,12 +75,11 @@ int parse_row(const int64_t* row, int T, const int8_t* arity, int V, int null_id
             break;
         }
         PlanNode nd;
-        nd.sample = sample; nd.token = tok; nd.col = col; nd.child0 = nd.child1 = -1; nd.level = 0;
+        nd.sample = image; nd.token = tok; nd.col = col; nd.child0 = nd.child1 = -1; nd.level = 0;
         const int ar = (tok == scene_id) ? 0 : arity[tok];
         // post-order numbering: a node gets its id when it completes, so reserve via the stack
         if (ar == 0) {
-            int id = (int)pl->nodes.size();
-            pl->nodes.push_back(nd);
+            int id = add_node(pl, nd);
             // deliver to parents
             for (;;) {
                 if (stack.empty()) { pl->roots.push_back(id); (void)base; return VQA_OK; }
@@ -73,8 +91,7 @@ int parse_row(const int64_t* row, int T, const int8_t* arity, int V, int null_id
                 // parent complete: it becomes a real node now
                 int pidx = f.node;
                 stack.pop_back();
-                id = (int)pl->nodes.size();
-                pl->nodes.push_back(pl->pending[pidx]);
+                id = add_node(pl, pl->pending[pidx]);
             }
         } else {
             pl->pending.push_back(nd);
@@ -146,25 +163,49 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
                                   const int8_t* arity, int32_t V, int32_t null_id,
                                   int32_t start_id, int32_t scene_id, int32_t C,
                                   int32_t wgrad_chunk, int32_t flags, vqa_plan** out) {
-    if (!programs || !arity || !out || N <= 0 || T <= 0 || V <= 0 || scene_id < 0 ||
-        scene_id >= V || C <= 0 || C % 128 != 0 || wgrad_chunk <= 0) {
+    return vqa_schedule_build_shared(programs, N, T, arity, V, null_id, start_id, scene_id, C, wgrad_chunk,
+                                     flags, nullptr, N, out);
+}
+
+extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int32_t T,
+                                         const int8_t* arity, int32_t V, int32_t null_id,
+                                         int32_t start_id, int32_t scene_id, int32_t C,
+                                         int32_t wgrad_chunk, int32_t flags, const int32_t* image_of_sample,
+                                         int32_t num_images, vqa_plan** out) {
+    if (!programs || !arity || !out || N <= 0 || T <= 0 || V <= 0 || V > 255 || scene_id < 0 ||
+        scene_id >= V || C <= 0 || C % 128 != 0 || wgrad_chunk <= 0 ||
+        (image_of_sample ? (num_images <= 0 || num_images >= (1 << 18)) : num_images != N)) {
         vqa_set_error("vqa_schedule_build: bad argument");
         return VQA_EINVAL;
+    }
+    if (image_of_sample) {
+        for (int i = 0; i < N; i++)
+            if (image_of_sample[i] < 0 || image_of_sample[i] >= num_images) {
+                vqa_set_error("vqa_schedule_build_shared: image index out of range");
+                return VQA_EINVAL;
+            }
+        if ((int64_t)N * (2 * T + 1) >= (1 << 19) - 1) {
+            vqa_set_error("vqa_schedule_build_shared: batch too large for shared-image scheduling");
+            return VQA_EINVAL;
+        }
     }
     vqa_plan* pl = new (std::nothrow) vqa_plan();
     if (!pl) { vqa_set_error("out of host memory"); return VQA_EINVAL; }
     pl->N = N; pl->T = T; pl->C = C; pl->V = V;
+    pl->M = num_images; pl->shared = image_of_sample != nullptr;
     pl->used.assign((size_t)N * T, 0.0f);
     pl->nodes.reserve((size_t)N * (T + 1));
     pl->roots.reserve(N);
     for (int i = 0; i < N; i++) {
         pl->pending.clear();
         int rc = parse_row(programs + (size_t)i * T, T, arity, V, null_id, start_id, scene_id, i,
-                           pl, pl->used.data() + (size_t)i * T);
+                           image_of_sample ? image_of_sample[i] : i, pl, pl->used.data() + (size_t)i * T);
         if (rc) { delete pl; return rc; }
     }
     pl->pending.clear();
     pl->pending.shrink_to_fit();
+    pl->interned.clear();
+    const int M = pl->M;
 
     const int NV = (int)pl->nodes.size();
     // kind indices
@@ -185,11 +226,11 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
     if (flags & VQA_PLAN_BALANCE) balance_levels(pl, 512 / (C / 128));
 
     // arena slots
-    pl->slot_F = 0; pl->slot_S0 = N; pl->slot_Y = 2 * N; pl->slot_H = 2 * N + NV;
-    pl->slot_P = 2 * N + 2 * NV; pl->slots_fwd = 2 * N + 2 * NV + nb;
+    pl->slot_F = 0; pl->slot_S0 = M; pl->slot_Y = 2 * M; pl->slot_H = 2 * M + NV;
+    pl->slot_P = 2 * M + 2 * NV; pl->slots_fwd = 2 * M + 2 * NV + nb;
     pl->slot_dZ = pl->slots_fwd; pl->slot_dH = pl->slot_dZ + NV; pl->slot_dP = pl->slot_dH + NV;
-    pl->slot_dFp = pl->slot_dP + nb; pl->slot_dF = pl->slot_dFp + ns; pl->slot_dS0 = pl->slot_dF + N;
-    pl->slots_total = pl->slot_dS0 + N;
+    pl->slot_dFp = pl->slot_dP + nb; pl->slot_dF = pl->slot_dFp + ns; pl->slot_dS0 = pl->slot_dF + M;
+    pl->slots_total = pl->shared ? pl->slots_fwd : pl->slot_dS0 + M;
 
     // level buckets: nodes of a level sorted by (token, node id)
     pl->level_nodes.assign(pl->num_levels, {});
@@ -247,13 +288,13 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
                           pl->nodes[v].token);
             // backward: dH = dgrad_conv2(dZ) * (H > 0)
             lv.off_dgrad2 = (int)b.size();
-            for (int v : nodes)
+            if (!pl->shared) for (int v : nodes)
                 push_tile(b, pl->slot_dZ + v, -1, pl->slot_dH + v, -1, -1, pl->slot_H + v, -1,
                           pl->nodes[v].token);
             // d(input) = (dgrad_conv1(dH) + dZ) * (input > 0); a scene node's input is the shared
             // stem map, so its gradient goes unmasked to a per-node slot and is summed later
             lv.off_dgrad1 = (int)b.size();
-            for (int v : nodes) {
+            if (!pl->shared) for (int v : nodes) {
                 const PlanNode& nd = pl->nodes[v];
                 int dst, mask;
                 if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
@@ -264,7 +305,7 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
         }
         if (!(flags & VQA_PLAN_SKIP_SEPARATE)) {
             lv.off_dproj = (int)b.size();
-            for (int v : bins) {
+            if (!pl->shared) for (int v : bins) {
                 const PlanNode& nd = pl->nodes[v];
                 push_tile(b, pl->slot_dP + pl->bin_index[v], -1, pl->slot_dZ + nd.child0,
                           pl->slot_dZ + nd.child1, -1, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
@@ -284,7 +325,7 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
                 b.insert(b.end(), w, w + 12);
             }
             lv.off_fused_bwd = (int)b.size();
-            for (int v : nodes) {
+            if (!pl->shared) for (int v : nodes) {
                 const PlanNode& nd = pl->nodes[v];
                 int dst, mask;
                 if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
@@ -306,18 +347,24 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
     auto sec = [&](int id) { pl->sec_off[id] = (int)b.size(); };
     auto endsec = [&](int id, int count) { pl->sec_cnt[id] = count; };
     sec(VQA_SEC_STEM0_TILES);
-    for (int i = 0; i < N; i++) push_tile(b, i, -1, pl->slot_S0 + i, -1, -1, -1, -1, 0);
-    endsec(VQA_SEC_STEM0_TILES, N);
+    for (int i = 0; i < M; i++) push_tile(b, i, -1, pl->slot_S0 + i, -1, -1, -1, -1, 0);
+    endsec(VQA_SEC_STEM0_TILES, M);
     sec(VQA_SEC_STEM1_TILES);
-    for (int i = 0; i < N; i++) push_tile(b, pl->slot_S0 + i, -1, pl->slot_F + i, -1, -1, -1, -1, 0);
-    endsec(VQA_SEC_STEM1_TILES, N);
+    for (int i = 0; i < M; i++) push_tile(b, pl->slot_S0 + i, -1, pl->slot_F + i, -1, -1, -1, -1, 0);
+    endsec(VQA_SEC_STEM1_TILES, M);
     sec(VQA_SEC_STEM1_DGRAD_TILES);
-    for (int i = 0; i < N; i++)
-        push_tile(b, pl->slot_dF + i, -1, pl->slot_dS0 + i, -1, -1, pl->slot_S0 + i, -1, 0);
-    endsec(VQA_SEC_STEM1_DGRAD_TILES, N);
+    if (!pl->shared)
+        for (int i = 0; i < N; i++)
+            push_tile(b, pl->slot_dF + i, -1, pl->slot_dS0 + i, -1, -1, pl->slot_S0 + i, -1, 0);
+    endsec(VQA_SEC_STEM1_DGRAD_TILES, pl->shared ? 0 : N);
     sec(VQA_SEC_CLS_FWD_TILES);
     for (int i = 0; i < N; i++) push_tile(b, pl->slot_Y + pl->roots[i], -1, i, -1, -1, -1, -1, 0);
     endsec(VQA_SEC_CLS_FWD_TILES, N);
+    if (pl->shared) {      // forward only: no backward sections (their counts stay zero)
+        if (b.empty()) b.push_back(0);
+        *out = pl;
+        return VQA_OK;
+    }
     sec(VQA_SEC_CLS_DGRAD_TILES);
     for (int i = 0; i < N; i++)
         push_tile(b, i, -1, pl->slot_dZ + pl->roots[i], -1, -1, pl->slot_Y + pl->roots[i], -1, 0);
@@ -440,6 +487,7 @@ extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
     o->blob_words = (int)pl->blob.size();
     o->wgrad_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
     o->max_level_tiles = pl->max_level_tiles;
+    o->num_images = pl->M;
     {   // one block of 8192 floats per tap and workgroup of the largest weight-gradient launch
         const int cc = pl->C / 128, os = pl->C / 64;
         o->wgrad_partial_blocks = std::max(pl->sec_cnt[VQA_SEC_WG_ITEMS] * os * cc * 9,

@@ -107,9 +107,9 @@ class _CallState(dict):
 
 class _ExecFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, x, program, need_grad, *params):
+    def forward(ctx, net, x, program, need_grad, image_index, *params):
         ctx.net = net
-        st = net._run_forward(x, program, need_grad)
+        st = net._run_forward(x, program, need_grad, image_index)
         # the output must not stay reachable from ctx: output -> grad_fn -> ctx -> state -> output is
         # a reference cycle that only the cyclic GC frees, and GBs of arena would pile up meanwhile
         logits = st.pop('logits')
@@ -123,7 +123,7 @@ class _ExecFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         grads = ctx.net._run_backward(ctx.state, dlogits)
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class ModuleNet(nn.Module):
@@ -316,7 +316,34 @@ class ModuleNet(nn.Module):
         _lib.load()
         params = [p for _, p in self._param_groups()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _ExecFn.apply(self, x, program, need_grad, *params)
+        if not need_grad and N > 1 and x.stride(0) == 0 and self.precision == 'bf16':
+            # MAPO candidate scoring (Train_model.py:343-344): feats[i].unsqueeze(0).expand(K, ...) is
+            # one image under K programs.  The stem runs once and subtrees the programs share are
+            # computed once.
+            return self.score_candidates(x[:1], program, torch.zeros(N, dtype=torch.int32))
+        return _ExecFn.apply(self, x, program, need_grad, None, *params)
+
+    def score_candidates(self, x, program, image_index):
+        """Inference-only scoring of candidate programs that share images: `x` holds the M distinct
+        feature maps [M, Cin, 14, 14], `program` the N programs [N, T] and image_index[n] the image
+        program n runs on.  Returns logits [N, A], the same values as forward() on x[image_index]
+        (same kernels, same order of operations per node).  One call can score the candidates of a
+        whole batch of questions; the reference's loop calls the executor once per question."""
+        if not (type(program) is torch.Tensor and program.dim() == 2):
+            raise ValueError('Unregonized program format')
+        if not x.is_cuda:
+            raise RuntimeError('vqa_amd.ModuleNet runs on an MI355X only: features must be a CUDA/HIP '
+                               'tensor (no CPU fallback)')
+        if self.precision != 'bf16':
+            raise NotImplementedError('shared-image scoring is built for the bf16 path')
+        img = torch.as_tensor(image_index).detach().to('cpu', torch.int32).contiguous()
+        if img.numel() != program.size(0):
+            raise ValueError('image_index must have one entry per program')
+        if img.numel() and (int(img.min()) < 0 or int(img.max()) >= x.size(0)):
+            raise IndexError('image_index out of range')
+        _lib.load()
+        with torch.no_grad():
+            return _ExecFn.apply(self, x, program, False, img.numpy(), *[p for _, p in self._param_groups()])
 
     def _conv(self, st, src, dst, w, tiles_sec, taps, k_chunks, n_out, src_geo, dst_geo, **kw):
         off, cnt = st['plan'].section(tiles_sec)
@@ -353,14 +380,15 @@ class ModuleNet(nn.Module):
             t = self._stem_tile_cache[key] = torch.from_numpy(rows.reshape(-1)).to(dev)
         return t
 
-    def _run_forward(self, x, program, need_grad):
+    def _run_forward(self, x, program, need_grad, image_index=None):
         """Order matters for the host/device overlap: the programs start their way to the host on a
         side stream, the stem (which does not depend on them) is enqueued, and only then does the
         host wait for the programs, parse them and upload the tile lists - under the stem kernels
         instead of in front of an idle device."""
         d = self._dims
         dev = x.device
-        N, c, p_, cpad = x.size(0), d['c'], d['p'], d['cin_pad']
+        # M feature maps, N programs: M == N unless programs share images (score_candidates)
+        M, N, c, p_, cpad = x.size(0), program.size(0), d['c'], d['p'], d['cin_pad']
         if x.dim() != 4 or tuple(x.shape[1:]) != (d['cin'], 14, 14):
             raise ValueError('features must be [N, %d, 14, 14]' % d['cin'])
         if self.precision == 'fp32':
@@ -401,18 +429,18 @@ class ModuleNet(nn.Module):
             st['pk'] = pk = self._pack_weights(dev)
             # stem: two conv3x3 + bias + ReLU over the whole batch (Module_Model.py:55-64,239)
             slot = (HW * c, c)
-            stem_elems = 2 * N * HW * c
+            stem_elems = 2 * M * HW * c
             arena_full = ws.get_capacity('arena', stem_elems, torch.bfloat16, dev)
             xs = x.detach().to(torch.float32).contiguous()
-            st['x_nhwc'] = xn = ws.get('x_nhwc', N * HW * cpad, torch.bfloat16, dev)
-            ops.nchw_to_nhwc(xs, xn, N, d['cin'], cpad)
-            stem_tiles = self._stem_tiles(N, dev)
+            st['x_nhwc'] = xn = ws.get('x_nhwc', M * HW * cpad, torch.bfloat16, dev)
+            ops.nchw_to_nhwc(xs, xn, M, d['cin'], cpad)
+            stem_tiles = self._stem_tiles(M, dev)
             geo = dict(taps=9, n_out=c, dst_slot_stride=slot[0], dst_pix_stride=slot[1], w_group_stride=0, relu=True)
-            ops.conv_tiles(xn, arena_full, pk['w_stem0'], stem_tiles, N, k_chunks=cpad // 128,
+            ops.conv_tiles(xn, arena_full, pk['w_stem0'], stem_tiles, M, k_chunks=cpad // 128,
                            src_slot_stride=HW * cpad, src_pix_stride=cpad, bias=pk['b_stem0'], **geo)
-            ops.conv_tiles(arena_full, arena_full, pk['w_stem1'], stem_tiles, N, k_chunks=c // 128,
+            ops.conv_tiles(arena_full, arena_full, pk['w_stem1'], stem_tiles, M, k_chunks=c // 128,
                            src_slot_stride=slot[0], src_pix_stride=slot[1], bias=pk['b_stem1'],
-                           tiles_offset=8 * N, **geo)
+                           tiles_offset=8 * M, **geo)
 
             # programs -> plan -> tile lists on the device
             if arrived is not None:
@@ -420,7 +448,8 @@ class ModuleNet(nn.Module):
             fused = c == 128 and self.fuse_residual_body
             plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk,
                         (_lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED) |
-                        (_lib.PLAN_BALANCE if self.balance_levels else 0))
+                        (_lib.PLAN_BALANCE if self.balance_levels else 0),
+                        image_index=image_index, num_images=M if image_index is not None else None)
             st['plan'] = plan
             info = plan.info
             self.last_token_counts = plan.token_counts()

@@ -14,7 +14,9 @@ from . import _lib, vocab as V
 class Plan:
     """Parsed + bucketed programs of one batch.  Owns the native plan handle."""
 
-    def __init__(self, programs, vocab, module_dim=128, wgrad_chunk=16, flags=0):
+    def __init__(self, programs, vocab, module_dim=128, wgrad_chunk=16, flags=0, image_index=None, num_images=None):
+        """image_index: optional int array [N], the image each sample runs on; samples of one image
+        then share common subtrees and the plan is forward-only (vqa_schedule_build_shared)."""
         lib = _lib.load()
         prog = np.ascontiguousarray(np.asarray(programs), dtype=np.int64)
         if prog.ndim != 2:
@@ -24,10 +26,20 @@ class Plan:
         self._lib = lib
         self._h = C.c_void_p()
         n, t = prog.shape
-        _lib.check(lib.vqa_schedule_build(
-            prog.ctypes.data_as(_lib.i64p), n, t, arity.ctypes.data_as(_lib.i8p), len(arity),
-            t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk, flags,
-            C.byref(self._h)))
+        if image_index is None:
+            _lib.check(lib.vqa_schedule_build(
+                prog.ctypes.data_as(_lib.i64p), n, t, arity.ctypes.data_as(_lib.i8p), len(arity),
+                t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk, flags,
+                C.byref(self._h)))
+        else:
+            img = np.ascontiguousarray(np.asarray(image_index), dtype=np.int32)
+            if img.shape != (n,):
+                raise ValueError('image_index must have one entry per program')
+            m = int(num_images) if num_images is not None else int(img.max()) + 1
+            _lib.check(lib.vqa_schedule_build_shared(
+                prog.ctypes.data_as(_lib.i64p), n, t, arity.ctypes.data_as(_lib.i8p), len(arity),
+                t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk, flags,
+                img.ctypes.data_as(_lib.i32p), m, C.byref(self._h)))
         self.info = _lib.PlanInfo()
         _lib.check(lib.vqa_plan_get_info(self._h, C.byref(self.info)))
         self.N, self.T, self.C = n, t, module_dim
