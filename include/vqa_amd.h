@@ -117,7 +117,7 @@ enum {
     VQA_SEC_COUNT
 };
 int vqa_plan_section(const vqa_plan* plan, int32_t id, int32_t* offset, int32_t* count);
-/* arena slot ids: which = 0 F(sample) 1 S0(sample) 2 Y(node) 3 H(node)
+/* arena slot ids (slot s is the map at arena + s * 196 * C elements): which = 0 F(sample) 1 S0(sample) 2 Y(node) 3 H(node)
  * 4 dZ(node) 5 dH(node) 6 dF(sample) 7 dS0(sample); returns slot or -1 */
 int32_t vqa_plan_slot(const vqa_plan* plan, int32_t which, int32_t index);
 

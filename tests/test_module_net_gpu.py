@@ -1,7 +1,7 @@
 """End-to-end parity of the HIP executor (through the C ABI) with the CPU oracle and with the golden
 vectors captured from the reference.
 
-Tolerance (BASELINE north star): bf16 path, logits and gradients within 2e-2 relative error, where
+Tolerance: bf16 path, logits and gradients within 2e-2 relative error, where
 relative error of a tensor is ||got - ref||_2 / ||ref||_2; used_fns and schedule bit-exact.
 
 Logits are compared with the fp32 oracle.  Gradients are compared with the oracle run with bf16
