@@ -31,6 +31,16 @@
 // Building blocks shared by the single-conv kernel and the fused residual-body kernel
 // ---------------------------------------------------------------------------------------------
 
+// Workgroup -> tile index.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its
+// own 4 MiB L2, and the tile lists are sorted by token: taken in order, every XCD would stream the
+// weights of every token of the level (0.6 MB per token and direction, tens of tokens) through its
+// L2 and thrash it.  Instead XCD x takes the x-th contiguous eighth of the list, so it sees an
+// eighth of the tokens.  (bijection for any n: XCD x owns n/8 tiles, one more if x < n % 8)
+__device__ __forceinline__ int xcd_tile_index(int block, int n) {
+    const int x = block & 7, j = block >> 3, q = n >> 3, r = n & 7;
+    return x * q + min(x, r) + j;
+}
+
 // zero the border of the halo image: the 68 positions no staging pass ever writes (row 0, columns
 // 0 and 15 of rows 1..14, rows 15 and 16)
 __device__ __forceinline__ void halo_zero_border(char* halo, int tid) {
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char halo[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const vqa_conv_tile t = p.tiles[blockIdx.x];
+    const vqa_conv_tile t = p.tiles[xcd_tile_index(blockIdx.x, p.num_tiles)];
     const int ntile = blockIdx.y;
 
     // this wave's weight stream: K-step s (32 channels of one tap) is two adjacent 1 KiB blocks
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     extern __shared__ __attribute__((aligned(16))) char halo[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const vqa_resblock_tile t = p.tiles[blockIdx.x];
+    const vqa_resblock_tile t = p.tiles[xcd_tile_index(blockIdx.x, p.num_tiles)];
     // diagnostics: shader-clock timestamps of the phase boundaries of every tile
     unsigned long long* stamps = p.phase_stamps ? p.phase_stamps + (int64_t)blockIdx.x * 8 : nullptr;
 #define STAMP(i) if (stamps && tid == 0) stamps[i] = __builtin_readcyclecounter()
