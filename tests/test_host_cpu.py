@@ -54,3 +54,26 @@ def test_no_cpu_fallback(vocab):
         net(torch.zeros(1, 128, 14, 14), torch.zeros(1, 4, 2, dtype=torch.int64))
     with pytest.raises(AttributeError):
         net(torch.zeros(1, 128, 14, 14), [[{'function': 'scene', 'inputs': [], 'value_inputs': []}]])
+
+
+def test_reference_checkpoint_round_trip(vocab, tmp_path):
+    """A checkpoint in the reference's layout (Functions.py:93-101 reads
+    `execution_engine_kwargs` / `execution_engine_state`) restores into the drop-in module, and
+    what the module saves is what a reference ModuleNet would load: same keys, shapes, values."""
+    from vqa_amd.module_net import ModuleNet
+    kwargs = dict(vocab=vocab, feature_dim=(128, 14, 14), stem_batchnorm=False, stem_num_layers=2, module_dim=128,
+                  module_residual=True, module_batchnorm=False, classifier_proj_dim=128,
+                  classifier_downsample='maxpool2', classifier_fc_layers=(128,), classifier_batchnorm=False,
+                  classifier_dropout=0)
+    dims = {k: kwargs[k] for k in ('feature_dim', 'module_dim', 'classifier_proj_dim', 'classifier_fc_layers')}
+    state = synth.synth_state_dict(3, vocab, **dims)
+    path = str(tmp_path / 'ee.pt')
+    torch.save({'execution_engine_kwargs': kwargs, 'execution_engine_state': state}, path)
+    ck = torch.load(path, map_location=lambda storage, loc: storage, weights_only=True)
+    net = ModuleNet(False, **ck['execution_engine_kwargs'])
+    net.load_state_dict(ck['execution_engine_state'])
+    out = net.state_dict()
+    assert list(out) == list(state)
+    for k in state:
+        assert torch.equal(out[k], state[k]), k
+    net.share_memory()                      # Train_model.py:224

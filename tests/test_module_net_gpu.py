@@ -342,3 +342,51 @@ def test_score_candidates_shares_images_and_subtrees(vocab):
     assert rel(shared, ref) <= TOL
     with pytest.raises(IndexError):
         net.score_candidates(x.cuda(), prog.cuda(), img + 1)
+
+
+def test_fp32_three_adam_steps_track_the_oracle(vocab):
+    """Drop-in training: three steps of the reference's loop (Train_model.py:306-315, Adam lr 1e-4,
+    weight_decay 5e-5, :165-167) on the fp32 HIP path and on the oracle, different batch each step;
+    the parameter vector stays within 1e-3, tokens never used keep their initial values."""
+    from vqa_amd.module_net import ModuleNet
+    dims = small_dims(128)
+    sd = synth.synth_state_dict(51, vocab, **dims)
+    net = ModuleNet(False, vocab, **dims)
+    net.load_state_dict(sd)
+    net.cuda().train()
+    net.precision = 'fp32'
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=5e-5)
+    ref = ModuleNetRef(vocab, sd)
+    ropt = torch.optim.Adam([dict.__getitem__(ref.p, k) for k in ref.p], lr=1e-4, weight_decay=5e-5)
+    ever = set()
+    for step in range(3):
+        prog = synth.synth_programs(60 + step, 16, vocab, max_len=12, max_nodes=9)
+        x, ans = synth.synth_features(60 + step, 16, dims['feature_dim']), synth.synth_answers(60 + step, 16)
+        xt, pt, at = torch.from_numpy(x), torch.from_numpy(prog), torch.from_numpy(ans)
+        opt.zero_grad()
+        F.cross_entropy(net(xt.cuda(), pt.cuda()), at.cuda()).backward()
+        ever |= {k for k, p in net.named_parameters() if p.grad is not None}
+        opt.step()
+        ropt.zero_grad()
+        F.cross_entropy(ref(xt, pt), at).backward()
+        ropt.step()
+    torch.cuda.synchronize()
+    # Adam divides by sqrt(v): an element whose gradient is at noise level still moves by ~lr per step,
+    # in a direction noise decides, so single tensors are compared by absolute distance (at most
+    # 2 * lr per step per element), the whole parameter vector at 1e-3 and the resulting logits at 2e-2.
+    num = den = 0.0
+    for k, p in net.named_parameters():
+        r = dict.__getitem__(ref.p, k).detach()
+        dlt = (p.detach().cpu() - r)
+        assert dlt.abs().max().item() <= 3 * 2e-4 + 1e-7, k
+        num += dlt.double().pow(2).sum().item()
+        den += r.double().pow(2).sum().item()
+        if k not in ever:
+            assert torch.equal(p.detach().cpu(), sd[k]), k
+    assert len(ever) < len(list(net.parameters()))          # some token never appeared
+    assert (num / den) ** 0.5 <= 1e-3
+    prog = torch.from_numpy(synth.synth_programs(70, 16, vocab, max_len=12, max_nodes=9))
+    x = torch.from_numpy(synth.synth_features(70, 16, dims['feature_dim']))
+    with torch.no_grad():
+        # the noise-directed moves above feed back into the logits: 7.5e-3 measured
+        assert rel(net(x.cuda(), prog.cuda()), ref(x, prog)) <= 2e-2
