@@ -5,10 +5,12 @@
 //
 // The contraction runs over pixels, which is the slow axis of the channels-last maps, so both MFMA
 // operands are read from LDS with the transposing read (ds_read_b64_tr_b16).  One workgroup
-// (8 waves) owns a work item (<= wgrad_chunk nodes of one weight group) x 64 output channels x
-// 128 source channels; wave w owns source channels [16w, 16w+16) x 4 tiles of 16 output channels x
-// every tap, so its accumulators (taps x 4 tiles) stay in registers across all nodes of the item
-// and leave once.  Leaving as fp32 atomics keeps a CU busy for ~60 us per workgroup (one 256-byte
+// (4 waves) owns a work item (<= wgrad_chunk nodes of one weight group) x 64 output channels x
+// 64 source channels; wave w owns source channels [16w, 16w+16) of that half x 4 tiles of 16 output
+// channels x every tap, so its accumulators (taps x 4 tiles) stay in registers across all nodes of
+// the item and leave once.  The quarter-of-a-node shape keeps LDS at 76 KB, so two independent
+// workgroups share a CU and one stages its next node while the other is in its MFMA phase (with
+// one 8-wave workgroup per CU every wave staged at the same time and the matrix pipe idled).  Leaving as fp32 atomics keeps a CU busy for ~60 us per workgroup (one 256-byte
 // atomic instruction per ~50 ns per CU) with nothing else resident to hide it; leaving as plain
 // 16-byte stores into a per-workgroup partial block costs a few us, and vqa_wgrad_reduce then sums
 // the blocks of each group straight into torch's weight layout (which also makes the result
@@ -21,40 +23,41 @@
 #include "plan.h"
 #include "prof.h"
 
-#define XH_STRIDE 288
+#define XH_STRIDE 160                        // 64 channels + 32 bytes
 #define XH_POS 264
-#define XH_BYTES (XH_POS * XH_STRIDE)        // 76032
+#define XH_BYTES (XH_POS * XH_STRIDE)        // 42240
 #define DY_STRIDE 160
 #define DY_POS 224
 #define DY_BYTES (DY_POS * DY_STRIDE)        // 35840
 #define WGRAD_LDS (XH_BYTES + DY_BYTES)
 
 template <int TAPS>
-__global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
+__global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xh = smem;
     char* dyt = smem + XH_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4, q = l15 >> 2, pp = lane & 3;
     const vqa_wgrad_item it = p.items[blockIdx.x];
-    const int oslice = blockIdx.y, kchunk = blockIdx.z;
+    const int oslice = blockIdx.y, kchunk = blockIdx.z >> 1, khalf = blockIdx.z & 1;
 
-    for (int i = tid; i < WGRAD_LDS / 16; i += 512) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < WGRAD_LDS / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
 
     int which = 0, choff = kchunk * 128;
     if (p.pair_chunks > 0) { which = kchunk / p.pair_chunks; choff = (kchunk % p.pair_chunks) * 128; }
+    choff += khalf * 64;
     const int32_t* sslots = which ? p.src1_slots : p.src_slots;
 
     // Prefetch registers are named scalars (not arrays): loop-carried arrays end up in scratch.
-    uint4 x0, x1, x2, x3, x4, x5, x6, d0, d1, d2, d3;
+    uint4 x0, x1, x2, x3, x4, x5, x6, d0, d1, d2, d3, d4, d5, d6;
 #define XLOAD(i, var)                                                                          \
     {                                                                                          \
-        const int e = tid + 512 * i, pix = min(e >> 4, VQA_HW - 1), pc = e & 15;               \
+        const int e = tid + 256 * i, pix = min(e >> 3, VQA_HW - 1), pc = e & 7;                \
         var = *(const uint4*)(sp + (int64_t)pix * p.src_pix_stride * 2 + pc * 16);             \
     }
 #define DLOAD(i, var)                                                                          \
     {                                                                                          \
-        const int e = tid + 512 * i, pix = min(e >> 3, VQA_HW - 1), pc = e & 7;                \
+        const int e = tid + 256 * i, pix = min(e >> 3, VQA_HW - 1), pc = e & 7;                \
         var = *(const uint4*)(dp + (int64_t)pix * p.dy_pix_stride * 2 + pc * 16);              \
     }
 #define LOAD_NODE(n)                                                                           \
@@ -63,12 +66,12 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
         const char* sp = (const char*)p.src + ((int64_t)ss * p.src_slot_stride + choff) * 2;   \
         const char* dp = (const char*)p.dy + ((int64_t)ds * p.dy_slot_stride + oslice * 64) * 2; \
         XLOAD(0, x0) XLOAD(1, x1) XLOAD(2, x2) XLOAD(3, x3) XLOAD(4, x4) XLOAD(5, x5) XLOAD(6, x6) \
-        DLOAD(0, d0) DLOAD(1, d1) DLOAD(2, d2) DLOAD(3, d3)                                    \
+        DLOAD(0, d0) DLOAD(1, d1) DLOAD(2, d2) DLOAD(3, d3) DLOAD(4, d4) DLOAD(5, d5) DLOAD(6, d6) \
     }
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define XSTORE(i, var)                                                                         \
     {                                                                                          \
-        const int e = tid + 512 * i, pix = e >> 4, pc = e & 15;                                \
+        const int e = tid + 256 * i, pix = e >> 3, pc = e & 7;                                 \
         if (pix < VQA_HW) {                                                                    \
             const int y = pix / 14, x = pix - y * 14;                                          \
             *(uint4*)(xh + ((y + 1) * 16 + x + 1) * XH_STRIDE + pc * 16) = var;                \
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
     }
 #define DSTORE(i, var)                                                                         \
     {                                                                                          \
-        const int e = tid + 512 * i, pix = e >> 3, pc = e & 7;                                 \
+        const int e = tid + 256 * i, pix = e >> 3, pc = e & 7;                                 \
         if (pix < VQA_HW) {                                                                    \
             const int y = pix / 14, x = pix - y * 14;                                          \
             *(uint4*)(dyt + (y * 16 + x) * DY_STRIDE + pc * 16) = var;                         \
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
 #define STORE_NODE()                                                                           \
     {                                                                                          \
         XSTORE(0, x0) XSTORE(1, x1) XSTORE(2, x2) XSTORE(3, x3) XSTORE(4, x4) XSTORE(5, x5) XSTORE(6, x6) \
-        DSTORE(0, d0) DSTORE(1, d1) DSTORE(2, d2) DSTORE(3, d3)                                \
+        DSTORE(0, d0) DSTORE(1, d1) DSTORE(2, d2) DSTORE(3, d3) DSTORE(4, d4) DSTORE(5, d5) DSTORE(6, d6) \
     }
 
     f32x4 acc[TAPS][4];
@@ -103,12 +106,13 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
     const int xoff = (prow * 16 + pcol) * XH_STRIDE + (wave * 16 + 4 * pp) * 2;   // + tap, + kk, + r
     const int doff = (prow * 16 + pcol) * DY_STRIDE + (4 * pp) * 2;               // + 32*ot, + kk, + r
 
-    LOAD_NODE(0)
     for (int n = 0; n < it.count; n++) {
+        // no register prefetch across the MFMA phase: the partner workgroup on this CU covers the
+        // round trip, and 14 more live registers would spill
+        LOAD_NODE(n)
         __syncthreads();          // zero fill done / previous node's reads done
         STORE_NODE()
         __syncthreads();
-        LOAD_NODE(min(n + 1, it.count - 1))   // unconditional: a predicated prefetch spills
 #pragma unroll 1
         for (int kk = 0; kk < 7; kk++) {
             const char* xb = xh + xoff + kk * 32 * XH_STRIDE;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
     // accumulators out: row = source channel, col = output channel
     if (p.partial) {
         // block of this workgroup: [tap][64 output channels][128 source channels] fp32
-        float* part = p.partial + ((int64_t)(blockIdx.x * gridDim.y + oslice) * gridDim.z + kchunk) * (TAPS * 8192);
+        float* part = p.partial + ((int64_t)(blockIdx.x * gridDim.y + oslice) * (gridDim.z >> 1) + kchunk) * (TAPS * 8192) + khalf * 64;
 #pragma unroll
         for (int t = 0; t < TAPS; t++)
 #pragma unroll
@@ -159,22 +163,22 @@ __global__ __launch_bounds__(512) void wgrad_tiles_kernel(vqa_wgrad_params p) {
             for (int o = 0; o < 4; o++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int i = kchunk * 128 + wave * 16 + g * 4 + r;
+                    const int i = kchunk * 128 + khalf * 64 + wave * 16 + g * 4 + r;
                     const int oc = oslice * 64 + o * 16 + l15;
                     atomicAdd(dw + ((int64_t)t * k_in + i) * p.n_out + oc, acc[t][o][r]);
                 }
     }
 
-    if (p.db && kchunk == 0) {
+    if (p.db && kchunk == 0 && khalf == 0) {
         __syncthreads();
-        float* red = (float*)smem;       // [512][8]
+        float* red = (float*)smem;       // [256][8]
 #pragma unroll
         for (int j = 0; j < 8; j++) red[tid * 8 + j] = bsum[j];
         __syncthreads();
         if (tid < 64) {
             const int pc = tid >> 3, j = tid & 7;
             float s = 0.f;
-            for (int u = pc; u < 512; u += 8) s += red[u * 8 + j];
+            for (int u = pc; u < 256; u += 8) s += red[u * 8 + j];
             atomicAdd(p.db + (int64_t)it.group * p.n_out + oslice * 64 + tid, s);
         }
     }
@@ -195,7 +199,7 @@ extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* st
         (void)hipFuncSetAttribute((const void*)wgrad_tiles_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS);
         attr_set = true;
     }
-    dim3 grid(p->num_items, p->n_out / 64, p->k_chunks), block(512);
+    dim3 grid(p->num_items, p->n_out / 64, p->k_chunks * 2), block(256);
     VqaProfScope prof(taps == 9 ? VQA_K_WGRAD9 : VQA_K_WGRAD1,
                       2.0 * VQA_HW * taps * p->k_chunks * 128.0 * p->n_out * p->total_nodes,
                       (double)p->total_nodes * VQA_HW * 2.0 * (p->k_chunks * 128 + p->n_out), (hipStream_t)stream);
