@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--max-nodes', type=int, default=27)
     ap.add_argument('--batches', type=int, default=4, help='distinct resident synthetic batches cycled through')
     ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of vqa_amd.optim.FusedAdam")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=768, help='programs in the CPU baseline sample')
     return ap.parse_args()
@@ -95,7 +96,12 @@ def main():
         step_net = DataParallelExecutor(net)
     opt = None
     if not a.no_optimizer:
-        opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=5e-5, fused=True)   # Train_model.py:165-167
+        # Train_model.py:165-167: Adam, lr 1e-4, weight_decay 5e-5
+        if a.torch_adam:
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=5e-5, fused=True)
+        else:
+            from vqa_amd.optim import FusedAdam
+            opt = FusedAdam(net.parameters(), lr=1e-4, weight_decay=5e-5, executor=net)
     loss_fn = torch.nn.CrossEntropyLoss()
 
     # resident synthetic batches (seed = 1000*config + rank, config 3)
@@ -207,7 +213,7 @@ def main():
                                    'well-formed CLEVR-style programs (<=%d nodes, T=%d, mean %.1f nodes), '
                                    'features [N,1024,14,14] fp32 resident in HBM'
                                    % (' + RCCL gradient all-reduce' if world > 1 else '',
-                                      '' if a.no_optimizer else ' + fused Adam', a.batch, a.max_nodes, a.max_len,
+                                      '' if a.no_optimizer else (' + torch fused Adam' if a.torch_adam else ' + Adam (vqa_amd.optim.FusedAdam)'), a.batch, a.max_nodes, a.max_len,
                                       float(np.mean(nodes_step)) / a.batch),
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'model_tflops': flops * world * a.steps / dt / 1e12,

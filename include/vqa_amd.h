@@ -322,6 +322,29 @@ int vqa_slot_sum_mask_f32(float* arena, const int32_t* offsets, const int32_t* s
                           int64_t slot_elems, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Adam (Train_model.py:165-167,315: torch.optim.Adam, L2 weight decay) for the executor's
+ * parameters.  g = grad + wd p;  m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;
+ * p -= step_size * m / (sqrt(v) * inv_bc2_sqrt + eps), with step_size = lr / (1 - b1^t) and
+ * inv_bc2_sqrt = 1 / sqrt(1 - b2^t) per tensor (a token unused in a batch has no gradient, is left
+ * out of the table and keeps its own step count, as torch skips `grad is None`).
+ * vqa_adam_tensors: one launch over `num_chunks` chunks of 4096 elements (device tables).
+ * vqa_adam_fc1: the first linear layer's weight [F][P][196] (Module_Model.py:85-88), which also
+ * writes the bf16 [F][196][P] copy the executor's GEMM reads.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float* p; const float* g; float* m; float* v;
+    int64_t numel;
+    float step_size, inv_bc2_sqrt;
+} vqa_adam_tensor;
+typedef struct { int32_t tensor; int32_t pad; int64_t offset; } vqa_adam_chunk;
+
+int vqa_adam_tensors(const vqa_adam_tensor* tensors, const vqa_adam_chunk* chunks, int32_t num_chunks,
+                     float weight_decay, float beta1, float beta2, float eps, void* stream);
+int vqa_adam_fc1(float* p, const float* g, float* m, float* v, void* packed, int32_t F, int32_t P,
+                 float weight_decay, float beta1, float beta2, float eps, float step_size,
+                 float inv_bc2_sqrt, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing for the benchmark (no counterpart in the reference).  Every launch of an MFMA
  * kernel whose kind is enabled is bracketed by HIP events on its stream (two event records per
  * launch cost host time: enable only the kinds wanted).  vqa_prof_collect waits for

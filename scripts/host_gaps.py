@@ -17,7 +17,8 @@ vocab = V.make_vocab()
 net = ModuleNet(False, vocab); net.load_state_dict(synth.synth_state_dict(17, vocab)); net.cuda().train()
 net._run_forward = timed('forward host', net._run_forward)
 net._run_backward = timed('backward host', net._run_backward)
-opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=5e-5, fused=True)
+from vqa_amd.optim import FusedAdam
+opt = FusedAdam(net.parameters(), lr=1e-4, weight_decay=5e-5, executor=net) if os.environ.get('TORCH_ADAM') is None else torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=5e-5, fused=True)
 opt.step = timed('adam host', opt.step)
 B = 1024
 batches = []

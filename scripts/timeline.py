@@ -5,7 +5,7 @@ f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # a step ends with the optimizer's run of multi-tensor launches
-idx = [i for i, r in enumerate(rows) if 'FusedOptimizer' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'FusedOptimizer' in r['Kernel_Name'] or 'adam_tensors_kernel' in r['Kernel_Name']]
 ends = [i for j, i in enumerate(idx) if j + 1 == len(idx) or idx[j + 1] != i + 1]
 s, e = ends[-2] + 1, ends[-1] + 1
 t0 = int(rows[s]['Start_Timestamp'])

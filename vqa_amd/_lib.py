@@ -107,6 +107,9 @@ SIGNATURES = {
     'vqa_bias_act': (i32, [vp, vp, vp, i32, i32, i64, i64, i32, i32, i64, i32, vp]),
     'vqa_col_sum': (i32, [vp, vp, i32, i32, i64, i32, vp]),
     'vqa_slot_sum_mask': (i32, [vp, vp, vp, vp, vp, i32, i64, vp]),
+    'vqa_adam_tensors': (i32, [vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+    'vqa_adam_fc1': (i32, [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                         C.c_float, vp]),
     'vqa_prof_enable': (i32, [i32]),
     'vqa_prof_collect': (i32, [C.POINTER(C.c_double), i32]),
     'vqa_tree_forward': (i32, [vp, C.POINTER(TreeCtx), vp]),

@@ -1,0 +1,128 @@
+// Adam update of the executor's parameters (Train_model.py:165-167, 315: torch.optim.Adam with L2
+// weight decay), HBM-bound: 28 bytes of traffic per parameter.
+//
+//   g  = grad + weight_decay * p
+//   m  = m + (1 - beta1) * (g - m)
+//   v  = beta2 * v + (1 - beta2) * g * g
+//   p -= (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+//
+// Two kernels.  vqa_adam_tensors updates any number of tensors in one launch from a device table
+// (tensors whose token was not used in the batch have no gradient and are simply not in the table:
+// the reference's `grad is None` skip; each tensor carries its own step count).  vqa_adam_fc1
+// updates the first linear layer's weight - 88 % of the network's parameters - and in the same pass
+// writes the bf16, channels-last copy the GEMM reads (Layers.py:42-44 flattens c*196+hw, the
+// executor's maps are hw*P+c), which otherwise costs a second trip over the 411 MB tensor every step.
+#include "vqa_dev.h"
+#include "plan.h"
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float wd, float b1c, float b2,
+                                      float b2c, float step_size, float inv_bc2_sqrt, float eps) {
+    g += wd * p;
+    m += b1c * (g - m);
+    v = b2 * v + b2c * g * g;
+    p -= step_size * m / (sqrtf(v) * inv_bc2_sqrt + eps);
+}
+
+// chunk c: elements [offset, offset + 4096) of tensor chunks[c].tensor
+__global__ __launch_bounds__(256) void adam_tensors_kernel(const vqa_adam_tensor* __restrict__ tensors,
+                                                           const vqa_adam_chunk* __restrict__ chunks, float wd,
+                                                           float beta1, float beta2, float eps) {
+    const vqa_adam_chunk ck = chunks[blockIdx.x];
+    const vqa_adam_tensor t = tensors[ck.tensor];
+    const float b1c = 1.f - beta1, b2c = 1.f - beta2;
+    const int64_t end = min(ck.offset + (int64_t)4096, t.numel);
+    if ((t.numel & 3) == 0) {       // 16-byte accesses
+        for (int64_t e = ck.offset + threadIdx.x * 4; e < end; e += 1024) {
+            float4 p = *(float4*)(t.p + e), m = *(float4*)(t.m + e), v = *(float4*)(t.v + e);
+            const float4 g = *(const float4*)(t.g + e);
+            adam1(p.x, g.x, m.x, v.x, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+            adam1(p.y, g.y, m.y, v.y, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+            adam1(p.z, g.z, m.z, v.z, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+            adam1(p.w, g.w, m.w, v.w, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+            *(float4*)(t.p + e) = p; *(float4*)(t.m + e) = m; *(float4*)(t.v + e) = v;
+        }
+    } else {
+        for (int64_t e = ck.offset + threadIdx.x; e < end; e += 256) {
+            float p = t.p[e], m = t.m[e], v = t.v[e];
+            adam1(p, t.g[e], m, v, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+            t.p[e] = p; t.m[e] = m; t.v[e] = v;
+        }
+    }
+}
+
+extern "C" int vqa_adam_tensors(const vqa_adam_tensor* tensors, const vqa_adam_chunk* chunks, int32_t num_chunks,
+                                float weight_decay, float beta1, float beta2, float eps, void* stream) {
+    if (!tensors || !chunks || num_chunks < 0) { vqa_set_error("vqa_adam_tensors: bad argument"); return VQA_EINVAL; }
+    if (num_chunks == 0) return VQA_OK;
+    hipLaunchKernelGGL(adam_tensors_kernel, dim3(num_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks,
+                       weight_decay, beta1, beta2, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_adam_tensors: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}
+
+// First linear layer: p, g, m, v are [F][P][196] fp32 (the reference's layout); packed is bf16
+// [Fpad][196][P].  Block = one output row f x 64 channels: a contiguous [64][196] tile of each array
+// (16-byte accesses), the updated weights also rounded to bf16 into an LDS tile [channel][198] and
+// written out pixel-major, 16 bytes per lane - the layout pass of vqa_nchw_to_nhwc riding along.
+__global__ __launch_bounds__(256) void adam_fc1_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       bf16_t* __restrict__ packed, int P, float wd, float beta1,
+                                                       float beta2, float eps, float step_size, float inv_bc2_sqrt) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 198];
+    const int f = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int64_t base = ((int64_t)f * P + c0) * VQA_HW;
+    const float b1c = 1.f - beta1, b2c = 1.f - beta2;
+#pragma unroll 1
+    for (int i0 = 0; i0 < 13; i0 += 4) {
+        float4 pv[4], gv[4], mv[4], vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int q = min(tid + 256 * (i0 + i), 64 * 49 - 1);       // float4 index in the tile
+            pv[i] = *(const float4*)(p + base + q * 4); gv[i] = *(const float4*)(g + base + q * 4);
+            mv[i] = *(const float4*)(m + base + q * 4); vv[i] = *(const float4*)(v + base + q * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int q = tid + 256 * (i0 + i);
+            if (i0 + i < 13 && q < 64 * 49) {
+                adam1(pv[i].x, gv[i].x, mv[i].x, vv[i].x, wd, b1c, beta2, b2c, step_size, inv_bc2_sqrt, eps);
+                adam1(pv[i].y, gv[i].y, mv[i].y, vv[i].y, wd, b1c, beta2, b2c, step_size, inv_bc2_sqrt, eps);
+                adam1(pv[i].z, gv[i].z, mv[i].z, vv[i].z, wd, b1c, beta2, b2c, step_size, inv_bc2_sqrt, eps);
+                adam1(pv[i].w, gv[i].w, mv[i].w, vv[i].w, wd, b1c, beta2, b2c, step_size, inv_bc2_sqrt, eps);
+                *(float4*)(p + base + q * 4) = pv[i]; *(float4*)(m + base + q * 4) = mv[i];
+                *(float4*)(v + base + q * 4) = vv[i];
+                const int c = q / 49, pix = (q - c * 49) * 4;
+                uint32_t* t = (uint32_t*)(tile + c * 198 + pix);
+                t[0] = cvt_pk_bf16((f32x2){pv[i].x, pv[i].y});
+                t[1] = cvt_pk_bf16((f32x2){pv[i].z, pv[i].w});
+            }
+        }
+    }
+    __syncthreads();
+    bf16_t* os = packed + (int64_t)f * VQA_HW * P + c0;
+    for (int idx = tid; idx < VQA_HW * 8; idx += 256) {
+        const int cg = (idx / VQA_HW) * 8, pix = idx - (idx / VQA_HW) * VQA_HW;
+        const bf16_t* t = tile + cg * 198 + pix;
+        uint4 o;
+        o.x = (uint32_t)t[0] | ((uint32_t)t[198] << 16);
+        o.y = (uint32_t)t[2 * 198] | ((uint32_t)t[3 * 198] << 16);
+        o.z = (uint32_t)t[4 * 198] | ((uint32_t)t[5 * 198] << 16);
+        o.w = (uint32_t)t[6 * 198] | ((uint32_t)t[7 * 198] << 16);
+        *(uint4*)(os + (int64_t)pix * P + cg) = o;
+    }
+}
+
+extern "C" int vqa_adam_fc1(float* p, const float* g, float* m, float* v, void* packed, int32_t F, int32_t P,
+                            float weight_decay, float beta1, float beta2, float eps, float step_size,
+                            float inv_bc2_sqrt, void* stream) {
+    if (!p || !g || !m || !v || !packed || F <= 0 || P <= 0 || P % 64 != 0) {
+        vqa_set_error("vqa_adam_fc1: bad argument");
+        return VQA_EINVAL;
+    }
+    hipLaunchKernelGGL(adam_fc1_kernel, dim3(P / 64, F), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (bf16_t*)packed, P, weight_decay, beta1, beta2, eps, step_size, inv_bc2_sqrt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_adam_fc1: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}

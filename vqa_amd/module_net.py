@@ -207,6 +207,8 @@ class ModuleNet(nn.Module):
         self._packed_key = None
         self._packed_stale = False
         self._packed = {}
+        self._fc1_packed = None       # persistent bf16 copy of the first linear layer's weight
+        self._fc1_fresh = False       # set by vqa_amd.optim.FusedAdam: that copy already holds the updated weight
         self.used_fns = None
         self.wgrad_chunk = 32
         # module width 128: both convolutions of a residual body run in one kernel; False selects
@@ -249,6 +251,8 @@ class ModuleNet(nn.Module):
         key = tuple((p.data_ptr(), p._version) for _, p in plist) + (str(device),)
         if key == self._packed_key and not self._packed_stale:
             return self._packed
+        fc1_ready = self._fc1_fresh and key == self._packed_key and self._fc1_packed is not None
+        self._fc1_fresh = False
         self._packed_stale = False
         d = self._dims
         c, p_, cin, cpad = d['c'], d['p'], d['cin'], d['cin_pad']
@@ -288,15 +292,26 @@ class ModuleNet(nn.Module):
             for li, idx in enumerate(self._fc_idx):
                 lin = self.classifier[idx]
                 fo, fi = lin.weight.shape
-                buf = torch.zeros(_rup(fo, 128), fi, dtype=torch.bfloat16, device=device)
                 if li == 0:
-                    ops.fc_weight_to_nhwc(lin.weight.contiguous(), buf, fo, _rup(fo, 128), p_)
+                    buf = self._fc1_packed_buffer(device)
+                    if not fc1_ready:
+                        ops.fc_weight_to_nhwc(lin.weight.contiguous(), buf, fo, _rup(fo, 128), p_)
                 else:
+                    buf = torch.zeros(_rup(fo, 128), fi, dtype=torch.bfloat16, device=device)
                     ops.cast_pad(lin.weight.contiguous(), buf, fo, fi, _rup(fo, 128), fi)
                 fcw.append(buf)
             pk['fc_w'] = fcw
         self._packed, self._packed_key = pk, key
         return pk
+
+    def _fc1_packed_buffer(self, device):
+        lin = self.classifier[self._fc_idx[0]]
+        fo, fi = lin.weight.shape
+        b = self._fc1_packed
+        if b is None or b.device != device or b.shape != (_rup(fo, 128), fi):
+            b = self._fc1_packed = torch.zeros(_rup(fo, 128), fi, dtype=torch.bfloat16, device=device)
+            self._fc1_fresh = False
+        return b
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, program):
