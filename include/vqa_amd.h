@@ -54,7 +54,7 @@ typedef struct {
     int32_t max_level_tiles;
     int32_t wgrad_partial_blocks; /* vqa_tree_backward's workspace, in blocks of 8192 floats */
     int32_t num_images;     /* N, or the image count of vqa_schedule_build_shared */
-    int32_t reserved[1];
+    int32_t num_exec_nodes; /* nodes that run: all the scene nodes of an image compute the same map, one does */
 } vqa_plan_info;
 
 /* programs: host int64 [N][T].  arity: int8 [V] (0 scene, 1 unary, 2 binary), indexed by token id
@@ -114,11 +114,13 @@ enum {
     VQA_SEC_WG_ITEMS, VQA_SEC_WG_SRC_C1, VQA_SEC_WG_DY_C1, VQA_SEC_WG_SRC_C2, VQA_SEC_WG_DY_C2,
     VQA_SEC_WG_PITEMS, VQA_SEC_WG_PSRC0, VQA_SEC_WG_PSRC1, VQA_SEC_WG_PDY,
     VQA_SEC_SAMPLE_ITEMS_FINE, /* as SAMPLE_ITEMS in chunks of max(1, min(wgrad_chunk, N/128)) samples */
+    VQA_SEC_SLOTS_SCDZ, VQA_SEC_SLOTS_SCY, /* per sample: dZ slot of its scene node that runs; that node's output slot */
     VQA_SEC_COUNT
 };
 int vqa_plan_section(const vqa_plan* plan, int32_t id, int32_t* offset, int32_t* count);
 /* arena slot ids (slot s is the map at arena + s * 196 * C elements): which = 0 F(sample) 1 S0(sample) 2 Y(node) 3 H(node)
- * 4 dZ(node) 5 dH(node) 6 dF(sample) 7 dS0(sample); returns slot or -1 */
+ * 4 dZ(node) 5 dH(node) 6 dF(sample) 7 dS0(sample) 8 P(binary node index); returns slot or -1.
+ * Scene nodes of one image share their Y / H / dH slots (one of them runs, see num_exec_nodes). */
 int32_t vqa_plan_slot(const vqa_plan* plan, int32_t which, int32_t index);
 
 /* ------------------------------------------------------------------------------------------
@@ -383,6 +385,9 @@ typedef struct {
  * lists are used, and g_conv1 / g_conv2 / g_proj are fp32 accumulators [V][tap][k][n] that the
  * caller zeroes first and converts with vqa_unpack_conv_grad (wgrad_partial is not used). */
 #define VQA_TREE_F32 2
+/* vqa_tree_forward: level 0 (the scene modules, one tile per image, independent of the programs)
+ * was already run by the caller (vqa_resblock_tiles on its own tile list, before the plan existed) */
+#define VQA_TREE_SKIP_LEVEL0 4
 
 int vqa_tree_forward(const vqa_plan* plan, const vqa_tree_ctx* ctx, void* stream);
 /* input gradients level by level, scene fan-in, then all weight gradients */

@@ -37,13 +37,25 @@ def check_against_oracle(prog, vocab):
     np.testing.assert_array_equal(plan.roots(), roots)
     assert plan.info.num_nodes == len(nodes)
     assert plan.info.num_levels == nodes[:, 5].max() + 1
+    # launch lists: every node but the repeated scene nodes of a sample (all scene nodes of a sample
+    # compute the same map: the first one runs, the others share its output slots)
+    scene_tok = vocab['program_token_to_idx']['scene']
+    first = {}
+    for v in range(len(nodes)):
+        if nodes[v, 1] == scene_tok:
+            first.setdefault(int(nodes[v, 0]), v)
+    runs = [v for v in range(len(nodes)) if nodes[v, 1] != scene_tok or first[int(nodes[v, 0])] == v]
     seen = []
     for L in range(plan.info.num_levels):
         lv = plan.level_nodes(L)
-        want = sorted(np.nonzero(nodes[:, 5] == L)[0].tolist(), key=lambda v: (nodes[v, 1], v))
+        want = sorted([v for v in runs if nodes[v, 5] == L], key=lambda v: (nodes[v, 1], v))
         assert lv.tolist() == want
         seen += lv.tolist()
-    assert sorted(seen) == list(range(len(nodes)))
+    assert sorted(seen) == runs and plan.info.num_exec_nodes == len(runs)
+    for v in range(len(nodes)):
+        if nodes[v, 1] == scene_tok:
+            assert plan.slot('Y', v) == plan.slot('Y', first[int(nodes[v, 0])])
+            assert plan.slot('H', v) == plan.slot('H', first[int(nodes[v, 0])])
     np.testing.assert_array_equal(plan.token_counts(), np.bincount(nodes[:, 1], minlength=len(vocab['program_token_to_idx'])))
     scene = vocab['program_token_to_idx']['scene']
     assert plan.info.num_scene == int((nodes[:, 1] == scene).sum())
@@ -85,7 +97,7 @@ def test_worst_case_sizes(vocab):
     assert (nodes[:, 0] == 0).sum() == 2 * T + 1
     assert (nodes[:, 0] == 1).sum() == T + 1
     assert (nodes[:, 0] == 2).sum() == 1
-    assert plan.info.slots_fwd == 2 * 3 + 2 * len(nodes) + T
+    assert plan.info.slots_fwd == 4 * 3 + 2 * len(nodes) + T
 
 
 def test_errors(vocab):
@@ -105,7 +117,7 @@ def test_blob_sections_and_slots(vocab):
     off, cnt = plan.section('CLS_FWD_TILES')
     tiles = blob[off:off + cnt * 8].reshape(cnt, 8)
     assert cnt == n
-    np.testing.assert_array_equal(tiles[:, 0], 2 * n + plan.roots())     # Y(root) gathered
+    np.testing.assert_array_equal(tiles[:, 0], [plan.slot('Y', r) for r in plan.roots()])     # Y(root) gathered
     np.testing.assert_array_equal(tiles[:, 2], np.arange(n))
     off, cnt = plan.section('SCENE_OFFSETS')
     offs = blob[off:off + cnt]
@@ -114,8 +126,11 @@ def test_blob_sections_and_slots(vocab):
     np.testing.assert_array_equal(np.diff(offs), per_sample)
     off, cnt = plan.section('WG_ITEMS')
     items = blob[off:off + cnt * 4].reshape(cnt, 4)
-    assert items[:, 2].sum() == nv and items[:, 2].max() <= 16
-    assert plan.slot('Y', 0) == 2 * n and plan.slot('H', 0) == 2 * n + nv
+    assert items[:, 2].sum() == plan.info.num_exec_nodes and items[:, 2].max() <= 16
+    assert plan.slot('F', 3) == 3 and plan.slot('S0', 3) == n + 3
+    assert plan.slot('Y', 0) == 2 * n + nodes[0, 0] and plan.slot('H', 0) == 3 * n + nodes[0, 0]   # node 0 is a scene node
+    nonscene = int(np.nonzero(nodes[:, 1] != vocab['program_token_to_idx']['scene'])[0][0])
+    assert plan.slot('Y', nonscene) == 4 * n + nonscene and plan.slot('H', nonscene) == 4 * n + nv + nonscene
     assert plan.info.slots_total > plan.info.slots_fwd
 
 
@@ -148,10 +163,14 @@ def test_balanced_levels_are_a_valid_schedule(vocab):
                 assert lv[c] < lv[v]
     sizes = np.bincount(lv, minlength=p1.info.num_levels)
     assert sizes.sum() == len(n1) and (sizes > 0).all()
-    assert sizes.max() < np.bincount(n0[:, 5]).max()
+    assert sizes[1:].max() < np.bincount(n0[:, 5])[1:].max()
     for L in range(p1.info.num_levels):
         ids = p1.level_nodes(L)
-        assert sorted(ids.tolist()) == np.nonzero(lv == L)[0].tolist()
+        if L == 0:      # scene nodes stay in level 0, one launch entry per sample
+            assert (n1[ids, 1] == vocab['program_token_to_idx']['scene']).all()
+            assert sorted(n1[ids, 0].tolist()) == sorted(set(n1[lv == 0, 0].tolist()))
+        else:
+            assert sorted(ids.tolist()) == np.nonzero(lv == L)[0].tolist()
         toks = n1[ids, 1]
         assert (np.diff(toks) >= 0).all()               # still grouped by token inside a level
     np.testing.assert_array_equal(p0.used_fns(), p1.used_fns())

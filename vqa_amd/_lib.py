@@ -17,8 +17,7 @@ class PlanInfo(C.Structure):
     _fields_ = [(n, i32) for n in ('N', 'T', 'C', 'num_nodes', 'num_scene', 'num_unary',
                                    'num_binary', 'num_levels', 'slots_fwd', 'slots_total',
                                    'blob_words', 'wgrad_items', 'max_level_tiles',
-                                   'wgrad_partial_blocks', 'num_images')] + \
-               [('reserved', i32 * 1)]
+                                   'wgrad_partial_blocks', 'num_images', 'num_exec_nodes')]
 
 
 class ConvParams(C.Structure):
@@ -65,10 +64,10 @@ SEC = {name: i for i, name in enumerate((
     'STEM0_TILES', 'STEM1_TILES', 'STEM1_DGRAD_TILES', 'CLS_FWD_TILES', 'CLS_DGRAD_TILES',
     'SLOTS_IDENT', 'SLOTS_S0', 'SLOTS_F', 'SLOTS_DF', 'SLOTS_DS0', 'SLOTS_ROOTY', 'SAMPLE_ITEMS',
     'SCENE_OFFSETS', 'SCENE_SRC', 'WG_ITEMS', 'WG_SRC_C1', 'WG_DY_C1', 'WG_SRC_C2', 'WG_DY_C2',
-    'WG_PITEMS', 'WG_PSRC0', 'WG_PSRC1', 'WG_PDY', 'SAMPLE_ITEMS_FINE'))}
+    'WG_PITEMS', 'WG_PSRC0', 'WG_PSRC1', 'WG_PDY', 'SAMPLE_ITEMS_FINE', 'SLOTS_SCDZ', 'SLOTS_SCY'))}
 
 CONV_BIAS, CONV_RELU = 1, 2
-TREE_UNFUSED, TREE_F32 = 1, 2
+TREE_UNFUSED, TREE_F32, TREE_SKIP_LEVEL0 = 1, 2, 4
 PLAN_SKIP_SEPARATE, PLAN_SKIP_FUSED, PLAN_BALANCE = 1, 2, 4
 
 # name -> (restype, argtypes); every symbol include/vqa_amd.h declares

@@ -25,11 +25,15 @@ struct vqa_plan {
     std::vector<int32_t> roots;       // node id of each sample's root
     std::vector<float> used;          // [N][T]
     std::vector<int32_t> bin_index, scene_index, token_counts;
+    std::vector<int32_t> rep;         // scene nodes: the first scene node of the same image (the one that runs); else itself
+    std::vector<int32_t> first_scene; // per image: its representative scene node, -1 if none
+    int num_exec = 0;                 // nodes that run (all but the aliased scene nodes)
     std::vector<std::vector<int>> level_nodes;
     std::vector<PlanLevel> levels;
     std::vector<int32_t> blob;
     int num_scene = 0, num_unary = 0, num_binary = 0, num_levels = 0, max_level_tiles = 0;
-    int slot_F = 0, slot_S0 = 0, slot_Y = 0, slot_H = 0, slot_P = 0, slots_fwd = 0;
+    int slot_F = 0, slot_S0 = 0, slot_Ysc = 0, slot_Hsc = 0, slot_Y = 0, slot_H = 0, slot_P = 0, slots_fwd = 0;
+    int slot_dHsc = 0;
     int slot_dZ = 0, slot_dH = 0, slot_dP = 0, slot_dFp = 0, slot_dF = 0, slot_dS0 = 0, slots_total = 0;
     bool has_separate = true, has_fused = true;   // which per-level tile lists the blob holds
     int sec_off[VQA_SEC_COUNT] = {0};

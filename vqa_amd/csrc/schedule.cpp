@@ -121,25 +121,41 @@ inline void push_tile(std::vector<int32_t>& b, int s0, int s1, int d0, int d1, i
 // with the least slack until it holds the even share of what is left, rounded up to whole rounds
 // (half a round once the share is that small).  Node ids, slots and results do not change; only
 // the launch a node runs in.
-static void balance_levels(vqa_plan* pl, int round) {
+static void balance_levels(vqa_plan* pl, int round, int scene_id) {
     const int NV = (int)pl->nodes.size(), L = pl->num_levels;
-    if (L <= 1 || round <= 0) return;
-    std::vector<int> parent(NV, -1), pending(NV, 0), latest(NV, L - 1);
+    if (L <= 2 || round <= 0) return;
+    // Scene nodes stay at level 0 (one launch over the images, before anything else); the rest is
+    // scheduled over levels 1..L-1.  A node may have several users (interned nodes of a shared
+    // image): users as a CSR list.
+    auto is_scene = [&](int v) { return pl->nodes[v].token == scene_id; };
+    std::vector<int> nuse(NV + 1, 0), pending(NV, 0), latest(NV, L - 1);
     for (int v = 0; v < NV; v++) {
         const PlanNode& nd = pl->nodes[v];
-        if (nd.child0 >= 0) { parent[nd.child0] = v; pending[v]++; }
-        if (nd.child1 >= 0) { parent[nd.child1] = v; pending[v]++; }
+        for (int c : {nd.child0, nd.child1})
+            if (c >= 0 && !is_scene(c)) { nuse[c + 1]++; pending[v]++; }
     }
-    for (int v = NV - 1; v >= 0; v--)            // a parent's id is larger than its children's
-        if (parent[v] >= 0) latest[v] = latest[parent[v]] - 1;
+    for (int v = 0; v < NV; v++) nuse[v + 1] += nuse[v];
+    std::vector<int> users(nuse[NV]), fill(nuse.begin(), nuse.end() - 1);
+    for (int v = 0; v < NV; v++) {
+        const PlanNode& nd = pl->nodes[v];
+        for (int c : {nd.child0, nd.child1})
+            if (c >= 0 && !is_scene(c)) users[fill[c]++] = v;
+    }
+    for (int v = NV - 1; v >= 0; v--)            // a user's id is larger than its inputs'
+        for (int k = nuse[v]; k < nuse[v + 1]; k++) latest[v] = std::min(latest[v], latest[users[k]] - 1);
     // ready nodes bucketed by latest level; within a bucket first in, first out
     std::vector<std::vector<int>> bucket(L);
     std::vector<size_t> head(L, 0);
-    for (int v = 0; v < NV; v++) if (pending[v] == 0) bucket[latest[v]].push_back(v);
+    int total = 0;
+    for (int v = 0; v < NV; v++) {
+        if (is_scene(v)) continue;
+        total++;
+        if (pending[v] == 0) bucket[latest[v]].push_back(v);
+    }
     std::vector<int> take;
-    int done = 0, lowest = 0;
-    for (int t = 0; t < L; t++) {
-        const int remaining = NV - done, share = (remaining + (L - t) - 1) / (L - t);
+    int done = 0, lowest = 1;
+    for (int t = 1; t < L; t++) {
+        const int remaining = total - done, share = (remaining + (L - t) - 1) / (L - t);
         const int target = share <= round / 2 ? round / 2 : (share + round - 1) / round * round;
         take.clear();
         while (lowest < L) {
@@ -149,10 +165,12 @@ static void balance_levels(vqa_plan* pl, int round) {
         }
         for (int v : take) {
             pl->nodes[v].level = t;
-            const int p = parent[v];
-            if (p >= 0 && --pending[p] == 0) {
-                bucket[latest[p]].push_back(p);
-                lowest = std::min(lowest, latest[p]);
+            for (int k = nuse[v]; k < nuse[v + 1]; k++) {
+                const int p = users[k];
+                if (--pending[p] == 0) {
+                    bucket[latest[p]].push_back(p);
+                    lowest = std::min(lowest, latest[p]);
+                }
             }
         }
         done += (int)take.size();
@@ -223,23 +241,44 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     }
     pl->num_scene = ns; pl->num_unary = nu; pl->num_binary = nb; pl->num_levels = maxlev + 1;
 
-    if (flags & VQA_PLAN_BALANCE) balance_levels(pl, 512 / (C / 128));
+    // Every scene node of an image computes the same map (same module, same input F): the first one
+    // runs, the others are aliases of it.  Node ids, and with them everything a caller indexes by
+    // node, stay as the reference's execution order numbers them.
+    pl->rep.resize(NV);
+    pl->first_scene.assign(M, -1);
+    pl->num_exec = NV;
+    for (int v = 0; v < NV; v++) {
+        const PlanNode& nd = pl->nodes[v];
+        if (nd.token != scene_id) { pl->rep[v] = v; continue; }
+        if (pl->first_scene[nd.sample] < 0) pl->first_scene[nd.sample] = v;
+        pl->rep[v] = pl->first_scene[nd.sample];
+        if (pl->rep[v] != v) pl->num_exec--;
+    }
+
+    if (flags & VQA_PLAN_BALANCE) balance_levels(pl, 512 / (C / 128), scene_id);
 
     // arena slots
-    pl->slot_F = 0; pl->slot_S0 = M; pl->slot_Y = 2 * M; pl->slot_H = 2 * M + NV;
-    pl->slot_P = 2 * M + 2 * NV; pl->slots_fwd = 2 * M + 2 * NV + nb;
-    pl->slot_dZ = pl->slots_fwd; pl->slot_dH = pl->slot_dZ + NV; pl->slot_dP = pl->slot_dH + NV;
-    pl->slot_dFp = pl->slot_dP + nb; pl->slot_dF = pl->slot_dFp + ns; pl->slot_dS0 = pl->slot_dF + M;
+    // F, S0 and the scene modules' maps come first, at places that depend on the image count only:
+    // the stem and the scene level can run before the programs are parsed
+    pl->slot_F = 0; pl->slot_S0 = M; pl->slot_Ysc = 2 * M; pl->slot_Hsc = 3 * M;
+    pl->slot_Y = 4 * M; pl->slot_H = 4 * M + NV;
+    pl->slot_P = 4 * M + 2 * NV; pl->slots_fwd = 4 * M + 2 * NV + nb;
+    pl->slot_dZ = pl->slots_fwd; pl->slot_dH = pl->slot_dZ + NV; pl->slot_dHsc = pl->slot_dH + NV;
+    pl->slot_dP = pl->slot_dHsc + M;
+    pl->slot_dFp = 0; pl->slot_dF = pl->slot_dP + nb; pl->slot_dS0 = pl->slot_dF + M;
     pl->slots_total = pl->shared ? pl->slots_fwd : pl->slot_dS0 + M;
+    auto y_slot = [&](int v) { return pl->nodes[v].token == scene_id ? pl->slot_Ysc + pl->nodes[v].sample : pl->slot_Y + v; };
+    auto h_slot = [&](int v) { return pl->nodes[v].token == scene_id ? pl->slot_Hsc + pl->nodes[v].sample : pl->slot_H + v; };
+    auto dh_slot = [&](int v) { return pl->nodes[v].token == scene_id ? pl->slot_dHsc + pl->nodes[v].sample : pl->slot_dH + v; };
 
     // level buckets: nodes of a level sorted by (token, node id)
     pl->level_nodes.assign(pl->num_levels, {});
     {
         std::vector<int> cnt(pl->num_levels, 0);
-        for (int v = 0; v < NV; v++) cnt[pl->nodes[v].level]++;
+        for (int v = 0; v < NV; v++) if (pl->rep[v] == v) cnt[pl->nodes[v].level]++;
         for (int L = 0; L < pl->num_levels; L++) pl->level_nodes[L].reserve(cnt[L]);
     }
-    for (int v = 0; v < NV; v++) pl->level_nodes[pl->nodes[v].level].push_back(v);
+    for (int v = 0; v < NV; v++) if (pl->rep[v] == v) pl->level_nodes[pl->nodes[v].level].push_back(v);
     {   // stable counting sort of each level by token
         std::vector<int> start(V + 1), tmp;
         for (auto& lv : pl->level_nodes) {
@@ -256,7 +295,7 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
         const PlanNode& nd = pl->nodes[v];
         if (nd.token == scene_id) return pl->slot_F + nd.sample;
         if (nd.child1 >= 0) return pl->slot_P + pl->bin_index[v];
-        return pl->slot_Y + nd.child0;
+        return y_slot(nd.child0);
     };
 
     std::vector<int32_t>& b = pl->blob;
@@ -276,20 +315,20 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
             lv.off_proj = (int)b.size();
             for (int v : bins) {
                 const PlanNode& nd = pl->nodes[v];
-                push_tile(b, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
+                push_tile(b, y_slot(nd.child0), y_slot(nd.child1),
                           pl->slot_P + pl->bin_index[v], -1, -1, -1, -1, nd.token);
             }
             lv.off_conv1 = (int)b.size();
             for (int v : nodes)
-                push_tile(b, in_slot(v), -1, pl->slot_H + v, -1, -1, -1, -1, pl->nodes[v].token);
+                push_tile(b, in_slot(v), -1, h_slot(v), -1, -1, -1, -1, pl->nodes[v].token);
             lv.off_conv2 = (int)b.size();
             for (int v : nodes)
-                push_tile(b, pl->slot_H + v, -1, pl->slot_Y + v, -1, in_slot(v), -1, -1,
+                push_tile(b, h_slot(v), -1, y_slot(v), -1, in_slot(v), -1, -1,
                           pl->nodes[v].token);
             // backward: dH = dgrad_conv2(dZ) * (H > 0)
             lv.off_dgrad2 = (int)b.size();
             if (!pl->shared) for (int v : nodes)
-                push_tile(b, pl->slot_dZ + v, -1, pl->slot_dH + v, -1, -1, pl->slot_H + v, -1,
+                push_tile(b, pl->slot_dZ + v, -1, dh_slot(v), -1, -1, h_slot(v), -1,
                           pl->nodes[v].token);
             // d(input) = (dgrad_conv1(dH) + dZ) * (input > 0); a scene node's input is the shared
             // stem map, so its gradient goes unmasked to a per-node slot and is summed later
@@ -297,10 +336,10 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
             if (!pl->shared) for (int v : nodes) {
                 const PlanNode& nd = pl->nodes[v];
                 int dst, mask;
-                if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
+                if (nd.token == scene_id) { dst = pl->slot_dF + nd.sample; mask = pl->slot_F + nd.sample; }
                 else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
-                else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
-                push_tile(b, pl->slot_dH + v, -1, dst, -1, pl->slot_dZ + v, mask, -1, nd.token);
+                else { dst = pl->slot_dZ + nd.child0; mask = y_slot(nd.child0); }
+                push_tile(b, dh_slot(v), -1, dst, -1, pl->slot_dZ + v, mask, -1, nd.token);
             }
         }
         if (!(flags & VQA_PLAN_SKIP_SEPARATE)) {
@@ -308,7 +347,7 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
             if (!pl->shared) for (int v : bins) {
                 const PlanNode& nd = pl->nodes[v];
                 push_tile(b, pl->slot_dP + pl->bin_index[v], -1, pl->slot_dZ + nd.child0,
-                          pl->slot_dZ + nd.child1, -1, pl->slot_Y + nd.child0, pl->slot_Y + nd.child1,
+                          pl->slot_dZ + nd.child1, -1, y_slot(nd.child0), y_slot(nd.child1),
                           nd.token);
             }
         }
@@ -320,21 +359,21 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
                 const PlanNode& nd = pl->nodes[v];
                 const int in = in_slot(v);
                 const bool bin = nd.child1 >= 0;
-                const int32_t w[12] = {bin ? pl->slot_Y + nd.child0 : in, bin ? pl->slot_Y + nd.child1 : -1,
-                                       pl->slot_Y + v, pl->slot_H + v, in, -1, -1, nd.token, -1, -1, -1, -1};
+                const int32_t w[12] = {bin ? y_slot(nd.child0) : in, bin ? y_slot(nd.child1) : -1,
+                                       y_slot(v), h_slot(v), in, -1, -1, nd.token, -1, -1, -1, -1};
                 b.insert(b.end(), w, w + 12);
             }
             lv.off_fused_bwd = (int)b.size();
             if (!pl->shared) for (int v : nodes) {
                 const PlanNode& nd = pl->nodes[v];
                 int dst, mask;
-                if (nd.token == scene_id) { dst = pl->slot_dFp + pl->scene_index[v]; mask = -1; }
+                if (nd.token == scene_id) { dst = pl->slot_dF + nd.sample; mask = pl->slot_F + nd.sample; }
                 else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
-                else { dst = pl->slot_dZ + nd.child0; mask = pl->slot_Y + nd.child0; }
+                else { dst = pl->slot_dZ + nd.child0; mask = y_slot(nd.child0); }
                 const bool bin = nd.child1 >= 0;
-                const int32_t w[12] = {pl->slot_dZ + v, -1, dst, pl->slot_dH + v, pl->slot_dZ + v, mask, pl->slot_H + v, nd.token,
+                const int32_t w[12] = {pl->slot_dZ + v, -1, dst, dh_slot(v), pl->slot_dZ + v, mask, h_slot(v), nd.token,
                                        bin ? pl->slot_dZ + nd.child0 : -1, bin ? pl->slot_dZ + nd.child1 : -1,
-                                       bin ? pl->slot_Y + nd.child0 : -1, bin ? pl->slot_Y + nd.child1 : -1};
+                                       bin ? y_slot(nd.child0) : -1, bin ? y_slot(nd.child1) : -1};
                 b.insert(b.end(), w, w + 12);
             }
         }
@@ -358,7 +397,7 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
             push_tile(b, pl->slot_dF + i, -1, pl->slot_dS0 + i, -1, -1, pl->slot_S0 + i, -1, 0);
     endsec(VQA_SEC_STEM1_DGRAD_TILES, pl->shared ? 0 : N);
     sec(VQA_SEC_CLS_FWD_TILES);
-    for (int i = 0; i < N; i++) push_tile(b, pl->slot_Y + pl->roots[i], -1, i, -1, -1, -1, -1, 0);
+    for (int i = 0; i < N; i++) push_tile(b, y_slot(pl->roots[i]), -1, i, -1, -1, -1, -1, 0);
     endsec(VQA_SEC_CLS_FWD_TILES, N);
     if (pl->shared) {      // forward only: no backward sections (their counts stay zero)
         if (b.empty()) b.push_back(0);
@@ -367,7 +406,7 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     }
     sec(VQA_SEC_CLS_DGRAD_TILES);
     for (int i = 0; i < N; i++)
-        push_tile(b, i, -1, pl->slot_dZ + pl->roots[i], -1, -1, pl->slot_Y + pl->roots[i], -1, 0);
+        push_tile(b, i, -1, pl->slot_dZ + pl->roots[i], -1, -1, y_slot(pl->roots[i]), -1, 0);
     endsec(VQA_SEC_CLS_DGRAD_TILES, N);
 
     auto slot_list = [&](int id, int base_slot) {
@@ -381,7 +420,7 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     slot_list(VQA_SEC_SLOTS_DF, pl->slot_dF);
     slot_list(VQA_SEC_SLOTS_DS0, pl->slot_dS0);
     sec(VQA_SEC_SLOTS_ROOTY);
-    for (int i = 0; i < N; i++) b.push_back(pl->slot_Y + pl->roots[i]);
+    for (int i = 0; i < N; i++) b.push_back(y_slot(pl->roots[i]));
     endsec(VQA_SEC_SLOTS_ROOTY, N);
 
     // sample-chunk work items (one weight group) for the stem / classifier weight gradients
@@ -406,7 +445,7 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     // scene fan-in (CSR by sample)
     std::vector<std::vector<int>> scenes(N);
     for (int v = 0; v < NV; v++)
-        if (pl->scene_index[v] >= 0) scenes[pl->nodes[v].sample].push_back(pl->slot_dFp + pl->scene_index[v]);
+        if (pl->scene_index[v] >= 0) scenes[pl->nodes[v].sample].push_back(pl->slot_dZ + v);
     sec(VQA_SEC_SCENE_OFFSETS);
     int run = 0;
     for (int i = 0; i < N; i++) { b.push_back(run); run += (int)scenes[i].size(); }
@@ -415,10 +454,17 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     sec(VQA_SEC_SCENE_SRC);
     for (int i = 0; i < N; i++) for (int s : scenes[i]) b.push_back(s);
     endsec(VQA_SEC_SCENE_SRC, run);
+    // ... summed into the representative's dZ slot, times (its output > 0)
+    sec(VQA_SEC_SLOTS_SCDZ);
+    for (int i = 0; i < N; i++) b.push_back(pl->slot_dZ + pl->first_scene[i]);
+    endsec(VQA_SEC_SLOTS_SCDZ, N);
+    sec(VQA_SEC_SLOTS_SCY);
+    for (int i = 0; i < N; i++) b.push_back(pl->slot_Ysc + i);
+    endsec(VQA_SEC_SLOTS_SCY, N);
 
     // module weight gradients: nodes grouped by token, cut into items of <= wgrad_chunk nodes
     std::vector<std::vector<int>> by_tok(V);
-    for (int v = 0; v < NV; v++) by_tok[pl->nodes[v].token].push_back(v);
+    for (int v = 0; v < NV; v++) if (pl->rep[v] == v) by_tok[pl->nodes[v].token].push_back(v);
     std::vector<int32_t> items, src_c1, dy_c1, src_c2, dy_c2;
     std::vector<int32_t> pitems, psrc0, psrc1, pdy;
     for (int t = 0; t < V; t++) {
@@ -430,8 +476,8 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
             items.insert(items.end(), it, it + 4);
             for (size_t k = s; k < s + it[2]; k++) {
                 int v = vs[k];
-                src_c1.push_back(in_slot(v)); dy_c1.push_back(pl->slot_dH + v);
-                src_c2.push_back(pl->slot_H + v); dy_c2.push_back(pl->slot_dZ + v);
+                src_c1.push_back(in_slot(v)); dy_c1.push_back(dh_slot(v));
+                src_c2.push_back(h_slot(v)); dy_c2.push_back(pl->slot_dZ + v);
             }
         }
         if (pl->nodes[vs[0]].child1 >= 0) {
@@ -441,8 +487,8 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
                 pitems.insert(pitems.end(), it, it + 4);
                 for (size_t k = s; k < s + it[2]; k++) {
                     int v = vs[k];
-                    psrc0.push_back(pl->slot_Y + pl->nodes[v].child0);
-                    psrc1.push_back(pl->slot_Y + pl->nodes[v].child1);
+                    psrc0.push_back(y_slot(pl->nodes[v].child0));
+                    psrc1.push_back(y_slot(pl->nodes[v].child1));
                     pdy.push_back(pl->slot_dP + pl->bin_index[v]);
                 }
             }
@@ -488,6 +534,7 @@ extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
     o->wgrad_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
     o->max_level_tiles = pl->max_level_tiles;
     o->num_images = pl->M;
+    o->num_exec_nodes = pl->num_exec;
     {   // one block of 8192 floats per tap and workgroup of the largest weight-gradient launch
         const int cc = pl->C / 128, os = pl->C / 64;
         o->wgrad_partial_blocks = std::max(pl->sec_cnt[VQA_SEC_WG_ITEMS] * os * cc * 9,
@@ -552,10 +599,16 @@ extern "C" int32_t vqa_plan_slot(const vqa_plan* pl, int32_t which, int32_t inde
     switch (which) {
         case 0: return index < pl->N ? pl->slot_F + index : -1;
         case 1: return index < pl->N ? pl->slot_S0 + index : -1;
-        case 2: return index < NV ? pl->slot_Y + index : -1;
-        case 3: return index < NV ? pl->slot_H + index : -1;
+        case 2: case 3: case 5: {
+            if (index >= NV) return -1;
+            const PlanNode& nd = pl->nodes[index];
+            const bool sc = pl->rep[index] != index || pl->first_scene[nd.sample] == index;   // a scene node
+            if (which == 2) return sc ? pl->slot_Ysc + nd.sample : pl->slot_Y + index;
+            if (which == 3) return sc ? pl->slot_Hsc + nd.sample : pl->slot_H + index;
+            return sc ? pl->slot_dHsc + nd.sample : pl->slot_dH + index;
+        }
         case 4: return index < NV ? pl->slot_dZ + index : -1;
-        case 5: return index < NV ? pl->slot_dH + index : -1;
+        case 8: return index < pl->num_binary ? pl->slot_P + index : -1;
         case 6: return index < pl->N ? pl->slot_dF + index : -1;
         case 7: return index < pl->N ? pl->slot_dS0 + index : -1;
         default: return -1;

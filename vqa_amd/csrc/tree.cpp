@@ -42,7 +42,7 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
         vqa_set_error("vqa_tree_forward: the plan was built without the tile lists of this path");
         return VQA_EINVAL;
     }
-    for (int L = 0; L < pl->num_levels; L++) {
+    for (int L = (c->flags & VQA_TREE_SKIP_LEVEL0) ? 1 : 0; L < pl->num_levels; L++) {
         const PlanLevel& lv = pl->levels[L];
         int rc;
         if (fused) {   // the whole node in one kernel
@@ -103,8 +103,21 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
         return VQA_EINVAL;
     }
     int rc;
+    const bool f32 = (c->flags & VQA_TREE_F32) != 0;
     for (int L = pl->num_levels - 1; L >= 0; L--) {
         const PlanLevel& lv = pl->levels[L];
+        if (L == 0) {
+            // every scene node of a sample is the same computation, run once: the gradients that its
+            // users wrote for each of them are summed into the one that ran, times (its output > 0)
+            const int32_t* bl = c->blob;
+            rc = f32 ? vqa_slot_sum_mask_f32((float*)c->arena, bl + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
+                                             bl + pl->sec_off[VQA_SEC_SCENE_SRC], bl + pl->sec_off[VQA_SEC_SLOTS_SCDZ],
+                                             bl + pl->sec_off[VQA_SEC_SLOTS_SCY], pl->N, slot, stream)
+                     : vqa_slot_sum_mask(c->arena, bl + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
+                                         bl + pl->sec_off[VQA_SEC_SCENE_SRC], bl + pl->sec_off[VQA_SEC_SLOTS_SCDZ],
+                                         bl + pl->sec_off[VQA_SEC_SLOTS_SCY], pl->N, slot, stream);
+            if (rc) return rc;
+        }
         if (fused) {
             vqa_resblock_params p = {};
             p.arena = c->arena;
@@ -135,16 +148,6 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
             if ((rc = conv(c, &p, 1, stream))) return rc;
         }
     }
-    // gradient of the stem output: sum over the scene nodes of each sample, times (F > 0)
-    const bool f32 = (c->flags & VQA_TREE_F32) != 0;
-    rc = f32 ? vqa_slot_sum_mask_f32((float*)c->arena, c->blob + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
-                                     c->blob + pl->sec_off[VQA_SEC_SCENE_SRC], c->blob + pl->sec_off[VQA_SEC_SLOTS_DF],
-                                     c->blob + pl->sec_off[VQA_SEC_SLOTS_F], pl->N, slot, stream)
-             : vqa_slot_sum_mask(c->arena, c->blob + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
-                                 c->blob + pl->sec_off[VQA_SEC_SCENE_SRC], c->blob + pl->sec_off[VQA_SEC_SLOTS_DF],
-                                 c->blob + pl->sec_off[VQA_SEC_SLOTS_F], pl->N, slot, stream);
-    if (rc) return rc;
-
     // weight gradients of every module, grouped by token
     vqa_wgrad_params w = {};
     w.src = w.dy = c->arena;
@@ -153,7 +156,7 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     w.n_out = pl->C;
     w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_ITEMS]);
     w.num_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
-    w.total_nodes = (int)pl->nodes.size();
+    w.total_nodes = pl->num_exec;
     w.k_chunks = cc;
     if (f32) {     // atomic accumulation into [V][tap][k][n] arrays the caller zeroed
         w.dw_group_stride = w33;

@@ -381,8 +381,11 @@ class ModuleNet(nn.Module):
         return ctx
 
     def _stem_tiles(self, N, dev):
-        """Tile lists of the two stem convolutions (image i -> S0 slot N+i -> F slot i); they depend
-        on the batch size only, so the stem can be enqueued before the programs are parsed."""
+        """Tile lists of the two stem convolutions (image i -> S0 slot N+i -> F slot i) and, behind
+        them, of the scene module (F slot i -> H slot 3N+i -> Y slot 2N+i, 12 words a tile): every
+        program's leaves are the scene module applied to the stem output (Module_Model.py:115-117,
+        171-176), one computation per image.  These depend on the batch size only, so the stem and
+        the scene level can be enqueued before the programs are parsed."""
         key = (N, str(dev))
         t = self._stem_tile_cache.get(key)
         if t is None:
@@ -391,8 +394,12 @@ class ModuleNet(nn.Module):
             rows[0, :, 0], rows[0, :, 2] = i, N + i
             rows[1, :, 0], rows[1, :, 2] = N + i, i
             rows[:, :, 7] = 0
+            scene = np.full((N, 12), -1, dtype=np.int32)
+            scene[:, 0], scene[:, 2], scene[:, 3], scene[:, 4] = i, 2 * N + i, 3 * N + i, i
+            scene[:, 7] = self.vocab['program_token_to_idx']['scene']
             self._stem_tile_cache.clear()
-            t = self._stem_tile_cache[key] = torch.from_numpy(rows.reshape(-1)).to(dev)
+            t = self._stem_tile_cache[key] = torch.from_numpy(
+                np.concatenate([rows.reshape(-1), scene.reshape(-1)])).to(dev)
         return t
 
     def _run_forward(self, x, program, need_grad, image_index=None):
@@ -444,7 +451,7 @@ class ModuleNet(nn.Module):
             st['pk'] = pk = self._pack_weights(dev)
             # stem: two conv3x3 + bias + ReLU over the whole batch (Module_Model.py:55-64,239)
             slot = (HW * c, c)
-            stem_elems = 2 * M * HW * c
+            stem_elems = 4 * M * HW * c      # stem maps S0, F and the scene module's H, Y per image
             arena_full = ws.get_capacity('arena', stem_elems, torch.bfloat16, dev)
             xs = x.detach().to(torch.float32).contiguous()
             st['x_nhwc'] = xn = ws.get('x_nhwc', M * HW * cpad, torch.bfloat16, dev)
@@ -456,11 +463,15 @@ class ModuleNet(nn.Module):
             ops.conv_tiles(arena_full, arena_full, pk['w_stem1'], stem_tiles, M, k_chunks=c // 128,
                            src_slot_stride=slot[0], src_pix_stride=slot[1], bias=pk['b_stem1'],
                            tiles_offset=8 * M, **geo)
+            fused = c == 128 and self.fuse_residual_body
+            if fused:       # the scene level needs no plan either
+                ops.resblock_tiles(arena_full, pk['w_conv1'], pk['w_conv2'], stem_tiles, M,
+                                   bias_first=pk['b_conv1'], bias_second=pk['b_conv2'], relu=True,
+                                   tiles_offset=16 * M)
 
             # programs -> plan -> tile lists on the device
             if arrived is not None:
                 arrived.synchronize()
-            fused = c == 128 and self.fuse_residual_body
             plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk,
                         (_lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED) |
                         (_lib.PLAN_BALANCE if self.balance_levels else 0),
@@ -499,6 +510,8 @@ class ModuleNet(nn.Module):
             raise
         # module trees, level by level
         tctx = self._tree_ctx(st, pk)
+        if fused:
+            tctx.flags |= _lib.TREE_SKIP_LEVEL0
         _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
         # classifier (Module_Model.py:66-93, default: no pooling): conv1x1 + ReLU on the gathered
         # roots, flatten, linear layers
@@ -721,8 +734,7 @@ class ModuleNet(nn.Module):
         if kind in ('H', 'Y'):
             return nchw(arena[plan.slot(kind, index)], c)
         if kind == 'P':
-            base = plan.slot('H', 0) + plan.info.num_nodes
-            return nchw(arena[base + index], c)
+            return nchw(arena[plan.slot('P', index)], c)
         if kind == 'C1':
             return nchw(st['c1'].view(-1, HW, d['p'])[:N], d['p'])
         if isinstance(kind, tuple) and kind[0] == 'FC':

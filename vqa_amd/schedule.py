@@ -103,13 +103,14 @@ class Plan:
         return off.value, cnt.value
 
     def slot(self, which, index):
-        names = {'F': 0, 'S0': 1, 'Y': 2, 'H': 3, 'dZ': 4, 'dH': 5, 'dF': 6, 'dS0': 7}
+        names = {'F': 0, 'S0': 1, 'Y': 2, 'H': 3, 'dZ': 4, 'dH': 5, 'dF': 6, 'dS0': 7, 'P': 8}
         return self._lib.vqa_plan_slot(self._h, names[which], index)
 
-    def flops(self, feature_dim=(1024, 14, 14), proj_dim=512, fc_dims=(1024,), num_answers=32):
+    def flops(self, feature_dim=(1024, 14, 14), proj_dim=512, fc_dims=(1024,), num_answers=32, executed=False):
         """Algorithmic FLOPs (2 per multiply-add) of forward and forward+backward for this
         batch: stem + parsed tree nodes + classifier; elementwise work is not counted and the
-        input features get no gradient."""
+        input features get no gradient.  executed=True counts what the device runs instead of what
+        the reference's per-node execution does (repeated scene nodes of a sample run once)."""
         hw, c, cin = feature_dim[1] * feature_dim[2], self.C, feature_dim[0]
         i = self.info
         f_stem0 = 2 * hw * 9 * cin * c
@@ -125,5 +126,8 @@ class Plan:
             f_cls += 2 * prev * f
             prev = f
         f_cls += 2 * prev * num_answers
-        fwd = self.N * (f_stem0 + f_stem1 + f_cls) + (i.num_scene + i.num_unary) * f_u + i.num_binary * f_b
+        scenes = i.num_scene
+        if executed:        # the scene nodes of a sample are one computation
+            scenes -= i.num_nodes - i.num_exec_nodes
+        fwd = self.N * (f_stem0 + f_stem1 + f_cls) + (scenes + i.num_unary) * f_u + i.num_binary * f_b
         return fwd, 3 * fwd - self.N * f_stem0
