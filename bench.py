@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--batches', type=int, default=4, help='distinct resident synthetic batches cycled through')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of vqa_amd.optim.FusedAdam")
+    ap.add_argument('--cpu-programs', action='store_true', help='hand the programs over as host tensors (the data loader\'s), '
+                    'so that the tile lists of a step are built while the device still runs the step before')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=768, help='programs in the CPU baseline sample')
     return ap.parse_args()
@@ -105,7 +107,7 @@ def main():
     loss_fn = torch.nn.CrossEntropyLoss()
 
     # resident synthetic batches (seed = 1000*config + rank, config 3)
-    batches, flops_step, nodes_step = [], [], []
+    batches, flops_step, flops_exec_step, nodes_step = [], [], [], []
     for b in range(max(1, a.batches)):
         seed = 3000 + rank + 100 * b
         prog = synth.synth_programs(seed, a.batch, vocab, max_len=a.max_len, max_nodes=a.max_nodes)
@@ -113,9 +115,10 @@ def main():
         x = torch.randn(a.batch, 1024, 14, 14, device=dev, generator=g).clamp_(min=0)
         ans = torch.from_numpy(synth.synth_answers(seed, a.batch)).to(dev)
         plan = Plan(prog, vocab, a.module_dim)
-        flops_step.append(plan.flops()[1])
+        flops_step.append(plan.flops()[1])                  # what the reference's per-node execution does
+        flops_exec_step.append(plan.flops(executed=True)[1])  # repeated scene nodes of a sample run once here
         nodes_step.append(plan.info.num_nodes)
-        batches.append((x, torch.from_numpy(prog).to(dev), ans))
+        batches.append((x, torch.from_numpy(prog) if a.cpu_programs else torch.from_numpy(prog).to(dev), ans))
 
     def step(i):
         x, prog, ans = batches[i % len(batches)]
@@ -211,12 +214,14 @@ def main():
             'config': {'workload': 'executor train step (fwd + cross-entropy + bwd%s%s), bf16 MFMA with fp32 '
                                    'accumulation, batch %d/GPU, default 117.5 M-parameter ModuleNet, random '
                                    'well-formed CLEVR-style programs (<=%d nodes, T=%d, mean %.1f nodes), '
-                                   'features [N,1024,14,14] fp32 resident in HBM'
+                                   'features [N,1024,14,14] fp32 resident in HBM, programs %s'
                                    % (' + RCCL gradient all-reduce' if world > 1 else '',
                                       '' if a.no_optimizer else (' + torch fused Adam' if a.torch_adam else ' + Adam (vqa_amd.optim.FusedAdam)'), a.batch, a.max_nodes, a.max_len,
-                                      float(np.mean(nodes_step)) / a.batch),
+                                      float(np.mean(nodes_step)) / a.batch,
+                                      'in host memory' if a.cpu_programs else 'resident in HBM'),
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'model_tflops': flops * world * a.steps / dt / 1e12,
+            'executed_tflops': sum(flops_exec_step[j] for j in idx) * world / dt / 1e12,
             'mfma_peak_frac': flops * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',

@@ -306,6 +306,10 @@ int vqa_cast_pad(const float* w, void* out, int32_t rows, int32_t cols, int32_t 
  * from_nhwc: fp32 [F][196*P] -> fp32 [F][P*196] */
 int vqa_fc_weight_to_nhwc(const float* w, void* out, int32_t F, int32_t Fpad, int32_t P, void* stream);
 int vqa_fc_grad_from_nhwc(const float* g, float* out, int32_t F, int32_t P, void* stream);
+/* Per-sample transposition bf16 [N][196][C] -> bf16 [N][C][196]: a channels-last activation in the
+ * flatten order of Layers.py:42-44, so that the weight gradient of the linear layer behind it
+ * (Module_Model.py:86-88) comes out of its GEMM in the reference's own layout.  C % 64 == 0. */
+int vqa_transpose_hw_c(const void* x, void* out, int32_t N, int32_t C, void* stream);
 /* out[rows][ld_out] = act(sum over `slabs` split-K slabs of acc fp32 [rows][ld_acc] + bias[col]) for
  * col < cols; out is bf16, or fp32 when out_f32 */
 int vqa_bias_act(const float* acc, const float* bias, void* out, int32_t rows, int32_t cols,

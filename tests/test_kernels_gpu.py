@@ -395,6 +395,12 @@ def test_layout_helpers():
     torch.cuda.synchronize()
     assert torch.equal(wn[:f].to(torch.float32).cpu(), bf(w).reshape(f, p, HW).permute(0, 2, 1).reshape(f, -1))
     assert torch.equal(g.cpu(), gin.reshape(f, HW, p).permute(0, 2, 1).reshape(f, -1))
+    # bf16 activations, channels-last -> the reference's flatten order
+    a = rnd((7, HW, 192), 45).to(torch.bfloat16)
+    at = torch.zeros(7, 192, HW, dtype=torch.bfloat16, device=dev())
+    ops.transpose_hw_c(a.to(dev()), at, 7, 192)
+    torch.cuda.synchronize()
+    assert torch.equal(at.cpu(), a.permute(0, 2, 1).contiguous())
 
 
 def test_bias_act_colsum_castpad():

@@ -103,6 +103,7 @@ SIGNATURES = {
     'vqa_cast_pad': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'vqa_fc_weight_to_nhwc': (i32, [vp, vp, i32, i32, i32, vp]),
     'vqa_fc_grad_from_nhwc': (i32, [vp, vp, i32, i32, vp]),
+    'vqa_transpose_hw_c': (i32, [vp, vp, i32, i32, vp]),
     'vqa_bias_act': (i32, [vp, vp, vp, i32, i32, i64, i64, i32, i32, i64, i32, vp]),
     'vqa_col_sum': (i32, [vp, vp, i32, i32, i64, i32, vp]),
     'vqa_slot_sum_mask': (i32, [vp, vp, vp, vp, vp, i32, i64, vp]),

@@ -101,6 +101,51 @@ extern "C" int vqa_nhwc_to_nchw(const void* x, float* out, int32_t N, int32_t C,
     return VQA_OK;
 }
 
+// in [n][196][C] bf16 -> out [n][C][196] bf16: the per-sample transposition that turns a flattened
+// channels-last activation into the reference's flatten order (Layers.py:42-44: c * 196 + hw).
+// Block = one sample x 64 channels; 16-byte loads (8 channels of a pixel), the tile in LDS as
+// bf16 [channel][198], 8-byte stores along the 25 KB contiguous output range of the block.
+__global__ __launch_bounds__(256) void transpose_hw_c_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                             int C) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 198];
+    const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    const bf16_t* is = in + (int64_t)n * VQA_HW * C + c0;
+    uint4 v[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const int idx = min(tid + 256 * i, VQA_HW * 8 - 1);
+        v[i] = *(const uint4*)(is + (int64_t)(idx >> 3) * C + (idx & 7) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const int idx = tid + 256 * i;
+        if (idx < VQA_HW * 8) {
+            bf16_t* t = tile + (idx & 7) * 8 * 198 + (idx >> 3);
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t[(2 * j) * 198] = (bf16_t)(w[j] & 0xffffu);
+                t[(2 * j + 1) * 198] = (bf16_t)(w[j] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    uint2* os = (uint2*)(out + ((int64_t)n * C + c0) * VQA_HW);
+    const uint32_t* tw = (const uint32_t*)tile;
+    for (int q = tid; q < 64 * 49; q += 256) {
+        const int c = q / 49, k = q - c * 49;
+        os[q] = make_uint2(tw[c * 99 + 2 * k], tw[c * 99 + 2 * k + 1]);
+    }
+}
+
+extern "C" int vqa_transpose_hw_c(const void* x, void* out, int32_t N, int32_t C, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || C % 64 != 0) { vqa_set_error("vqa_transpose_hw_c: bad argument"); return VQA_EINVAL; }
+    hipLaunchKernelGGL(transpose_hw_c_kernel, dim3(C / 64, N), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)out, C);
+    CHECK_LAUNCH("vqa_transpose_hw_c");
+    return VQA_OK;
+}
+
 extern "C" int vqa_fc_grad_from_nhwc(const float* g, float* out, int32_t F, int32_t P, void* stream) {
     if (!g || !out || F <= 0 || P <= 0 || P % 64 != 0) { vqa_set_error("vqa_fc_grad_from_nhwc: bad argument"); return VQA_EINVAL; }
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(P / 64, F), dim3(256), 0, (hipStream_t)stream, g, out, P);

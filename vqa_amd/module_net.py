@@ -783,14 +783,16 @@ class ModuleNet(nn.Module):
                 # feeds nothing else in this pass: it runs on the side stream, next to the small
                 # top-of-tree launches that follow and cannot fill the device on their own.  Under
                 # data parallelism its all-reduce is issued from there as well, first of all.
-                tmp = ws.get('fc0_gw', fo * fi, torch.float32, dev)
+                # The GEMM reads a copy of the activations in the reference's flatten order
+                # (Layers.py:42-44), so the 411 MB gradient is written once, in its final layout.
+                act_t = ws.get('fc0_act_t', np128 * fi, torch.bfloat16, dev)
                 cur, side = torch.cuda.current_stream(dev), self._side
                 fork = torch.cuda.Event()
                 fork.record(cur)
                 with torch.cuda.stream(side):
                     side.wait_event(fork)
-                    ops.gemm(g, acts[li], tmp, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
-                    ops.fc_grad_from_nhwc(tmp, gw, fo, p_)
+                    ops.transpose_hw_c(acts[li], act_t, np128, p_)
+                    ops.gemm(g, act_t, gw, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
                     if self.grad_ready_hook is not None:
                         self.grad_ready_hook(name + '.weight', gw)
                         emitted.add(name + '.weight')

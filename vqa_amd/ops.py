@@ -151,6 +151,12 @@ def fc_grad_from_nhwc(g, out, f, p):
     _lib.check(_lib.load().vqa_fc_grad_from_nhwc(_ptr(g), _ptr(out), f, p, _stream()))
 
 
+def transpose_hw_c(x, out, n, c):
+    """bf16 [n][196][c] -> bf16 [n][c][196]"""
+    assert x.dtype == out.dtype == torch.bfloat16 and x.numel() >= n * 196 * c and out.numel() >= n * 196 * c
+    _lib.check(_lib.load().vqa_transpose_hw_c(_ptr(x), _ptr(out), n, c, _stream()))
+
+
 def bias_act(acc, bias, out, rows, cols, ld_acc, ld_out, relu, slabs=1, slab_stride=0):
     _lib.check(_lib.load().vqa_bias_act(_ptr(acc), _ptr(bias), _ptr(out), rows, cols, ld_acc, ld_out,
                                         int(relu), slabs, slab_stride,
