@@ -7,6 +7,7 @@ C ABI of libvqa_amd.so.  Submodules below only hold parameters under the referen
 they are never called.  There is no CPU or eager-torch fallback: a CPU tensor or a missing
 library raises.
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -781,23 +782,26 @@ class ModuleNet(nn.Module):
             else:
                 # The weight gradient of the first linear layer (most of the network's parameters)
                 # feeds nothing else in this pass: it runs on the side stream, next to the small
-                # top-of-tree launches that follow and cannot fill the device on their own.  Under
+                # classifier and top-of-tree launches that cannot fill the device on their own.  Under
                 # data parallelism its all-reduce is issued from there as well, first of all.
                 # The GEMM reads a copy of the activations in the reference's flatten order
                 # (Layers.py:42-44), so the 411 MB gradient is written once, in its final layout.
                 act_t = ws.get('fc0_act_t', np128 * fi, torch.bfloat16, dev)
-                cur, side = torch.cuda.current_stream(dev), self._side
-                fork = torch.cuda.Event()
-                fork.record(cur)
-                with torch.cuda.stream(side):
-                    side.wait_event(fork)
-                    ops.transpose_hw_c(acts[li], act_t, np128, p_)
-                    ops.gemm(g, act_t, gw, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
-                    if self.grad_ready_hook is not None:
-                        self.grad_ready_hook(name + '.weight', gw)
-                        emitted.add(name + '.weight')
-                    side_done = torch.cuda.Event()
-                    side_done.record(side)
+
+                def fc1_weight_grad(g=g, g_ld=g_ld, gw=gw, li=li, name=name):
+                    cur, side = torch.cuda.current_stream(dev), self._side
+                    fork = torch.cuda.Event()
+                    fork.record(cur)
+                    with torch.cuda.stream(side):
+                        side.wait_event(fork)
+                        ops.transpose_hw_c(acts[li], act_t, np128, p_)
+                        ops.gemm(g, act_t, gw, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
+                        if self.grad_ready_hook is not None:
+                            self.grad_ready_hook(name + '.weight', gw)
+                            emitted.add(name + '.weight')
+                        done = torch.cuda.Event()
+                        done.record(side)
+                    return done
             grads[name + '.weight'] = gw
             # input gradient, masked by the ReLU that produced the input
             gin = ws.get('fc_gin%d' % li, np128 * fi, torch.bfloat16, dev)
@@ -807,6 +811,10 @@ class ModuleNet(nn.Module):
             ops.gemm(g, pk['fc_w'][li], gin, N, fi, kdim, lda=g_ld, ldb=fi, ldc=fi, b_kmajor=True,
                      out_bf16=True, mask=acts[li])
             g, g_ld = gin, fi
+            if li == 0:
+                # behind the input-gradient GEMM: two device-filling GEMMs side by side only slow
+                # each other down
+                side_done = fc1_weight_grad()
             if li > 0:
                 gb = torch.zeros(fi, **f32)
                 ops.col_sum(gin, gb, N, fi, fi)
