@@ -37,3 +37,12 @@ timed('forward (split-k 16)', fwd, F)
 timed('weight gradient', wgrad, F)
 timed('input gradient (masked)', dgrad, F)
 timed('both gradients, two streams', both, 2 * F)
+# the vendor library on the same shapes (bf16 in, bf16 out; fp32 out where torch offers it)
+xt = x  # [B][FI]
+timed('torch.mm forward bf16', lambda: torch.mm(x, w.t()), F)
+timed('torch.mm wgrad bf16 out', lambda: torch.mm(dy.t(), x), F)
+timed('torch.mm dgrad bf16 out', lambda: torch.mm(dy, w), F)
+try:
+    timed('torch.mm wgrad fp32 out', lambda: torch.mm(dy.t(), x, out_dtype=torch.float32), F)
+except Exception as e:
+    print('fp32-out mm unavailable:', type(e).__name__, str(e)[:100])
