@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of vqa_amd.optim.FusedAdam")
     ap.add_argument('--cpu-programs', action='store_true', help='hand the programs over as host tensors (the data loader\'s), '
                     'so that the tile lists of a step are built while the device still runs the step before')
+    ap.add_argument('--features', choices=['fp32', 'resident'], default='fp32',
+                    help="fp32: the loader's [N,1024,14,14] fp32 batches (default, the reference's input); resident: "
+                         'rows of a bf16 feature table held in HBM (vqa_amd.feed.ResidentFeatures), read in place')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=768, help='programs in the CPU baseline sample')
     return ap.parse_args()
@@ -119,6 +122,10 @@ def main():
         flops_exec_step.append(plan.flops(executed=True)[1])  # repeated scene nodes of a sample run once here
         nodes_step.append(plan.info.num_nodes)
         batches.append((x, torch.from_numpy(prog) if a.cpu_programs else torch.from_numpy(prog).to(dev), ans))
+    if a.features == 'resident':
+        from vqa_amd.feed import ResidentFeatures
+        table = ResidentFeatures(torch.cat([b[0] for b in batches]), dev)
+        batches = [(table.rows(np.arange(i * a.batch, (i + 1) * a.batch)), p_, an) for i, (_, p_, an) in enumerate(batches)]
 
     def step(i):
         x, prog, ans = batches[i % len(batches)]
@@ -214,10 +221,12 @@ def main():
             'config': {'workload': 'executor train step (fwd + cross-entropy + bwd%s%s), bf16 MFMA with fp32 '
                                    'accumulation, batch %d/GPU, default 117.5 M-parameter ModuleNet, random '
                                    'well-formed CLEVR-style programs (<=%d nodes, T=%d, mean %.1f nodes), '
-                                   'features [N,1024,14,14] fp32 resident in HBM, programs %s'
+                                   'features %s, programs %s'
                                    % (' + RCCL gradient all-reduce' if world > 1 else '',
                                       '' if a.no_optimizer else (' + torch fused Adam' if a.torch_adam else ' + Adam (vqa_amd.optim.FusedAdam)'), a.batch, a.max_nodes, a.max_len,
                                       float(np.mean(nodes_step)) / a.batch,
+                                      '[N,1024,14,14] fp32 resident in HBM' if a.features == 'fp32' else
+                                      'rows of a bf16 [R,196,1024] table resident in HBM, read in place',
                                       'in host memory' if a.cpu_programs else 'resident in HBM'),
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'model_tflops': flops * world * a.steps / dt / 1e12,

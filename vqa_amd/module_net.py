@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import _lib, ops, vocab as V
 from .schedule import Plan
+from .feed import FeatureRows
 
 HW = 196
 
@@ -332,7 +333,10 @@ class ModuleNet(nn.Module):
         _lib.load()
         params = [p for _, p in self._param_groups()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        if not need_grad and N > 1 and x.stride(0) == 0 and self.precision == 'bf16':
+        if isinstance(x, FeatureRows):
+            if self.precision != 'bf16':
+                x = x.dense()
+        elif not need_grad and N > 1 and x.stride(0) == 0 and self.precision == 'bf16':
             # MAPO candidate scoring (Train_model.py:343-344): feats[i].unsqueeze(0).expand(K, ...) is
             # one image under K programs.  The stem runs once and subtrees the programs share are
             # computed once.
@@ -380,6 +384,25 @@ class ModuleNet(nn.Module):
         ctx.C, ctx.V = self._dims['c'], len(self._tokens)
         ctx.flags = 0 if self.fuse_residual_body else _lib.TREE_UNFUSED
         return ctx
+
+    def _stem_input(self, x, ws, M, dev):
+        """The stem's input as bf16 [rows][196][cin_pad] plus, when the batch is a set of rows of a
+        resident table, their int32 row numbers.  Three forms are read in place, without a layout
+        pass: rows of a vqa_amd.feed.ResidentFeatures table, and a bf16 tensor in channels-last
+        memory format (what vqa_amd.feed.HostFeed yields).  Anything else is the reference's fp32
+        NCHW batch (Train_model.py:311) and goes through vqa_nchw_to_nhwc."""
+        d = self._dims
+        cin, cpad = d['cin'], d['cin_pad']
+        if isinstance(x, FeatureRows):
+            if cin != cpad or x.table.size(2) != cin or x.table.dtype != torch.bfloat16 or not x.table.is_contiguous():
+                raise ValueError('feature table must be contiguous bf16 [R, 196, %d]' % cpad)
+            return x.table, x.index
+        if (x.dtype == torch.bfloat16 and cin == cpad and x.stride() == (HW * cin, 1, 14 * cin, cin)):
+            return x.detach(), None
+        xs = x.detach().to(torch.float32).contiguous()
+        xn = ws.get('x_nhwc', M * HW * cpad, torch.bfloat16, dev)
+        ops.nchw_to_nhwc(xs, xn, M, cin, cpad)
+        return xn, None
 
     def _stem_tiles(self, N, dev):
         """Tile lists of the two stem convolutions (image i -> S0 slot N+i -> F slot i) and, behind
@@ -454,12 +477,16 @@ class ModuleNet(nn.Module):
             slot = (HW * c, c)
             stem_elems = 4 * M * HW * c      # stem maps S0, F and the scene module's H, Y per image
             arena_full = ws.get_capacity('arena', stem_elems, torch.bfloat16, dev)
-            xs = x.detach().to(torch.float32).contiguous()
-            st['x_nhwc'] = xn = ws.get('x_nhwc', M * HW * cpad, torch.bfloat16, dev)
-            ops.nchw_to_nhwc(xs, xn, M, d['cin'], cpad)
+            xn, rows = self._stem_input(x, ws, M, dev)
+            st['x_nhwc'], st['x_rows'] = xn, rows
             stem_tiles = self._stem_tiles(M, dev)
+            tiles0 = stem_tiles
+            if rows is not None:       # maps read in place from a resident table: source slot = table row
+                tiles0 = ws.get('stem0_tiles', 8 * M, torch.int32, dev)
+                tiles0.copy_(stem_tiles[:8 * M])
+                tiles0.view(M, 8)[:, 0] = rows
             geo = dict(taps=9, n_out=c, dst_slot_stride=slot[0], dst_pix_stride=slot[1], w_group_stride=0, relu=True)
-            ops.conv_tiles(xn, arena_full, pk['w_stem0'], stem_tiles, M, k_chunks=cpad // 128,
+            ops.conv_tiles(xn, arena_full, pk['w_stem0'], tiles0, M, k_chunks=cpad // 128,
                            src_slot_stride=HW * cpad, src_pix_stride=cpad, bias=pk['b_stem0'], **geo)
             ops.conv_tiles(arena_full, arena_full, pk['w_stem1'], stem_tiles, M, k_chunks=c // 128,
                            src_slot_stride=slot[0], src_pix_stride=slot[1], bias=pk['b_stem1'],
@@ -867,7 +894,8 @@ class ModuleNet(nn.Module):
         gw = torch.empty(c, c, 3, 3, **f32)
         ops.wgrad_reduce(part, (blob, fi_off), fi_cnt, 1, c, c // 128, 9, gw, 0)
         grads['stem.2.weight'], grads['stem.2.bias'] = gw, gs1b
-        ops.wgrad_tiles(st['x_nhwc'], arena, (blob, it_off), it_cnt, sec('SLOTS_IDENT'), sec('SLOTS_DS0'), None, gs0b,
+        x_slots = (st['x_rows'], 0) if st.get('x_rows') is not None else sec('SLOTS_IDENT')
+        ops.wgrad_tiles(st['x_nhwc'], arena, (blob, it_off), it_cnt, x_slots, sec('SLOTS_DS0'), None, gs0b,
                         taps=9, k_chunks=cpad // 128, n_out=c, src_slot_stride=HW * cpad, dy_slot_stride=HW * c,
                         src_pix_stride=cpad, dy_pix_stride=c, dw_group_stride=9 * cpad * c, total_nodes=N, partial=part)
         gw = torch.empty(c, cpad, 3, 3, **f32)
