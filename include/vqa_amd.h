@@ -55,6 +55,8 @@ typedef struct {
     int32_t wgrad_partial_blocks; /* vqa_tree_backward's workspace, in blocks of 8192 floats */
     int32_t num_images;     /* N, or the image count of vqa_schedule_build_shared */
     int32_t num_exec_nodes; /* nodes that run: all the scene nodes of an image compute the same map, one does */
+    int32_t blob_fwd_words; /* leading part of the blob that the forward pass reads */
+    int32_t blob_words_bound; /* upper bound of blob_words once the plan is finished (VQA_PLAN_DEFER_BACKWARD) */
 } vqa_plan_info;
 
 /* programs: host int64 [N][T].  arity: int8 [V] (0 scene, 1 unary, 2 binary), indexed by token id
@@ -70,6 +72,12 @@ typedef struct {
  * come in whole rounds of the device (256 CUs x 2 workgroups); the level count, node ids, slots and
  * results stay the same. */
 #define VQA_PLAN_BALANCE 4
+/* With VQA_PLAN_DEFER_BACKWARD the build returns once the forward part of the blob (blob_fwd_words,
+ * then equal to blob_words) is written: the caller uploads it and enqueues the forward pass, and
+ * vqa_plan_finish appends the backward tile lists and sections while the device is busy.  Until
+ * then the backward sections have count 0, vqa_tree_backward refuses the plan, and blob_words /
+ * wgrad_items / wgrad_partial_blocks describe the forward part only. */
+#define VQA_PLAN_DEFER_BACKWARD 8
 int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T, const int8_t* arity,
                        int32_t V, int32_t null_id, int32_t start_id, int32_t scene_id, int32_t C,
                        int32_t wgrad_chunk, int32_t flags, vqa_plan** out);
@@ -98,6 +106,10 @@ int vqa_plan_token_counts(const vqa_plan* plan, int32_t* out);
 int vqa_plan_roots(const vqa_plan* plan, int32_t* out);
 /* the descriptor blob to copy to the device before running the tree (blob_words int32) */
 int vqa_plan_blob(const vqa_plan* plan, int32_t* out);
+/* words [first, first + count) of the blob (the part vqa_plan_finish appended, say) */
+int vqa_plan_blob_range(const vqa_plan* plan, int32_t first, int32_t count, int32_t* out);
+/* completes a plan built with VQA_PLAN_DEFER_BACKWARD (no-op on a complete one) */
+int vqa_plan_finish(vqa_plan* plan);
 /* Sections of the blob that the host needs by name (the per-level tile lists are used by
  * vqa_tree_forward / vqa_tree_backward internally).  offset is in int32 words. */
 enum {

@@ -208,3 +208,31 @@ def test_shared_image_plan_interns_common_subtrees(vocab):
         assert tree(n0, r0[i]) == tree(n1, r1[i])
     with pytest.raises(ValueError):
         Plan(prog, vocab, image_index=img[:5])
+
+
+def test_deferred_backward_part_gives_the_same_blob(vocab):
+    """VQA_PLAN_DEFER_BACKWARD: the build returns with the forward part of the blob only;
+    vqa_plan_finish appends the rest.  Same blob, same sections as a one-step build."""
+    from vqa_amd import _lib
+    prog = synth.synth_programs(31, 200, vocab)
+    for base in (_lib.PLAN_SKIP_SEPARATE | _lib.PLAN_BALANCE, _lib.PLAN_SKIP_FUSED, 0):
+        whole = Plan(prog, vocab, flags=base)
+        part = Plan(prog, vocab, flags=base | _lib.PLAN_DEFER_BACKWARD)
+        nf = part.info.blob_fwd_words
+        assert part.info.blob_words == nf == whole.info.blob_fwd_words < whole.info.blob_words
+        assert whole.info.blob_words <= part.info.blob_words_bound
+        assert part.section('CLS_FWD_TILES') == whole.section('CLS_FWD_TILES')
+        assert part.section('WG_ITEMS')[1] == 0 and part.section('SLOTS_DF')[1] == 0
+        np.testing.assert_array_equal(part.blob(), whole.blob()[:nf])
+        part.finish()
+        part.finish()       # idempotent
+        assert part.info.blob_words == whole.info.blob_words
+        assert part.info.wgrad_partial_blocks == whole.info.wgrad_partial_blocks
+        np.testing.assert_array_equal(part.blob(), whole.blob())
+        for name in _lib.SEC:
+            assert part.section(name) == whole.section(name)
+        import torch
+        buf = torch.zeros(whole.info.blob_words, dtype=torch.int32)
+        part.blob_range_into(buf, nf, whole.info.blob_words - nf)
+        np.testing.assert_array_equal(buf.numpy()[nf:], whole.blob()[nf:])
+        assert (buf.numpy()[:nf] == 0).all()

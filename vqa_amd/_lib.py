@@ -17,7 +17,8 @@ class PlanInfo(C.Structure):
     _fields_ = [(n, i32) for n in ('N', 'T', 'C', 'num_nodes', 'num_scene', 'num_unary',
                                    'num_binary', 'num_levels', 'slots_fwd', 'slots_total',
                                    'blob_words', 'wgrad_items', 'max_level_tiles',
-                                   'wgrad_partial_blocks', 'num_images', 'num_exec_nodes')]
+                                   'wgrad_partial_blocks', 'num_images', 'num_exec_nodes',
+                                   'blob_fwd_words', 'blob_words_bound')]
 
 
 class ConvParams(C.Structure):
@@ -68,7 +69,7 @@ SEC = {name: i for i, name in enumerate((
 
 CONV_BIAS, CONV_RELU = 1, 2
 TREE_UNFUSED, TREE_F32, TREE_SKIP_LEVEL0 = 1, 2, 4
-PLAN_SKIP_SEPARATE, PLAN_SKIP_FUSED, PLAN_BALANCE = 1, 2, 4
+PLAN_SKIP_SEPARATE, PLAN_SKIP_FUSED, PLAN_BALANCE, PLAN_DEFER_BACKWARD = 1, 2, 4, 8
 
 # name -> (restype, argtypes); every symbol include/vqa_amd.h declares
 SIGNATURES = {
@@ -86,6 +87,8 @@ SIGNATURES = {
     'vqa_plan_token_counts': (i32, [vp, i32p]),
     'vqa_plan_roots': (i32, [vp, i32p]),
     'vqa_plan_blob': (i32, [vp, i32p]),
+    'vqa_plan_blob_range': (i32, [vp, i32, i32, i32p]),
+    'vqa_plan_finish': (i32, [vp]),
     'vqa_plan_section': (i32, [vp, i32, i32p, i32p]),
     'vqa_plan_slot': (i32, [vp, i32, i32]),
     'vqa_conv_tiles': (i32, [C.POINTER(ConvParams), i32, vp]),

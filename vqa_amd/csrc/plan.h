@@ -36,6 +36,10 @@ struct vqa_plan {
     int slot_dHsc = 0;
     int slot_dZ = 0, slot_dH = 0, slot_dP = 0, slot_dFp = 0, slot_dF = 0, slot_dS0 = 0, slots_total = 0;
     bool has_separate = true, has_fused = true;   // which per-level tile lists the blob holds
+    int scene_id = 0, wgrad_chunk = 0, flags = 0;  // build arguments the deferred backward part needs
+    bool finished = false;            // backward part of the blob written (or none: shared images)
+    int fwd_words = 0;                // blob words of the forward part
+    size_t blob_bound = 0;            // upper bound of the finished blob's size
     int sec_off[VQA_SEC_COUNT] = {0};
     int sec_cnt[VQA_SEC_COUNT] = {0};
 };

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 thread_local std::string g_vqa_error;
@@ -25,6 +26,49 @@ extern "C" int vqa_version(void) { return 100; }
 namespace {
 
 struct Frame { int node; int need; };
+
+// Freed plans are kept (a few of them) and reused by the next build: their node table and blob are
+// megabytes, and getting fresh pages for them from the kernel on every batch costs more than the
+// scheduling itself.
+std::mutex g_pool_mu;
+std::vector<vqa_plan*> g_pool;
+
+vqa_plan* plan_acquire() {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool.empty()) {
+            vqa_plan* p = g_pool.back();
+            g_pool.pop_back();
+            return p;
+        }
+    }
+    return new (std::nothrow) vqa_plan();
+}
+
+void plan_release(vqa_plan* p) {
+    if (!p) return;
+    // back to the state of a new plan, capacities kept
+    p->N = p->T = p->C = p->V = p->M = 0;
+    p->shared = false;
+    p->interned.clear();
+    p->nodes.clear(); p->pending.clear(); p->roots.clear(); p->used.clear();
+    p->bin_index.clear(); p->scene_index.clear(); p->token_counts.clear(); p->rep.clear(); p->first_scene.clear();
+    p->num_exec = 0;
+    for (auto& lv : p->level_nodes) lv.clear();
+    p->levels.clear(); p->blob.clear();
+    p->num_scene = p->num_unary = p->num_binary = p->num_levels = p->max_level_tiles = 0;
+    p->slot_F = p->slot_S0 = p->slot_Ysc = p->slot_Hsc = p->slot_Y = p->slot_H = p->slot_P = p->slots_fwd = 0;
+    p->slot_dHsc = p->slot_dZ = p->slot_dH = p->slot_dP = p->slot_dFp = p->slot_dF = p->slot_dS0 = p->slots_total = 0;
+    p->has_separate = p->has_fused = true;
+    p->scene_id = p->wgrad_chunk = p->flags = p->fwd_words = 0;
+    p->finished = false;
+    p->blob_bound = 0;
+    std::memset(p->sec_off, 0, sizeof(p->sec_off));
+    std::memset(p->sec_cnt, 0, sizeof(p->sec_cnt));
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() < 4) g_pool.push_back(p);
+    else delete p;
+}
 
 // A finished node becomes a row of the node table - or, when samples share images, the row that
 // already holds the same computation: same image, same token, same (already interned) inputs give
@@ -47,8 +91,8 @@ int add_node(vqa_plan* pl, const PlanNode& nd) {
 
 // Iterative form of the recursive helper: a stack of open nodes waiting for inputs.
 int parse_row(const int64_t* row, int T, const int8_t* arity, int V, int null_id, int start_id,
-              int scene_id, int sample, int image, vqa_plan* pl, float* used) {
-    std::vector<Frame> stack;
+              int scene_id, int sample, int image, vqa_plan* pl, float* used, std::vector<Frame>& stack) {
+    stack.clear();
     int j = 0;
     const int base = (int)pl->nodes.size();
     for (;;) {
@@ -106,6 +150,261 @@ inline void push_tile(std::vector<int32_t>& b, int s0, int s1, int d0, int d1, i
     b.resize(at + 8);            // capacity is reserved up front: no reallocation here
     int32_t* t = b.data() + at;
     t[0] = s0; t[1] = s1; t[2] = d0; t[3] = d1; t[4] = res; t[5] = m0; t[6] = m1; t[7] = wg;
+}
+
+// arena slots of a node's maps; all scene nodes of an image share the image's scene slots
+inline int y_slot(const vqa_plan* pl, int v) {
+    const PlanNode& nd = pl->nodes[v];
+    return nd.token == pl->scene_id ? pl->slot_Ysc + nd.sample : pl->slot_Y + v;
+}
+inline int h_slot(const vqa_plan* pl, int v) {
+    const PlanNode& nd = pl->nodes[v];
+    return nd.token == pl->scene_id ? pl->slot_Hsc + nd.sample : pl->slot_H + v;
+}
+inline int dh_slot(const vqa_plan* pl, int v) {
+    const PlanNode& nd = pl->nodes[v];
+    return nd.token == pl->scene_id ? pl->slot_dHsc + nd.sample : pl->slot_dH + v;
+}
+inline int in_slot(const vqa_plan* pl, int v) {   // slot the residual body of node v reads
+    const PlanNode& nd = pl->nodes[v];
+    if (nd.token == pl->scene_id) return pl->slot_F + nd.sample;
+    if (nd.child1 >= 0) return pl->slot_P + pl->bin_index[v];
+    return y_slot(pl, nd.child0);
+}
+
+// Forward half of the blob: what vqa_tree_forward and the classifier's gather read.  It comes first
+// so that a caller can upload it and start the forward launches while the backward half is still
+// being written (VQA_PLAN_DEFER_BACKWARD, vqa_plan_finish).
+void build_forward_part(vqa_plan* pl) {
+    std::vector<int32_t>& b = pl->blob;
+    const int N = pl->N, M = pl->M;
+    pl->levels.assign(pl->num_levels, {});
+    int max_tiles = 0;
+    for (int L = 0; L < pl->num_levels; L++) {
+        PlanLevel& lv = pl->levels[L];
+        const std::vector<int>& nodes = pl->level_nodes[L];
+        lv.count = (int)nodes.size();
+        max_tiles = std::max(max_tiles, lv.count);
+        // binary nodes of the level keep the same (token, id) order
+        lv.bcount = 0;
+        for (int v : nodes) lv.bcount += pl->nodes[v].child1 >= 0;
+        if (pl->has_separate) {   // one tile list per convolution pass
+            lv.off_proj = (int)b.size();
+            for (int v : nodes) {
+                const PlanNode& nd = pl->nodes[v];
+                if (nd.child1 < 0) continue;
+                push_tile(b, y_slot(pl, nd.child0), y_slot(pl, nd.child1),
+                          pl->slot_P + pl->bin_index[v], -1, -1, -1, -1, nd.token);
+            }
+            lv.off_conv1 = (int)b.size();
+            for (int v : nodes)
+                push_tile(b, in_slot(pl, v), -1, h_slot(pl, v), -1, -1, -1, -1, pl->nodes[v].token);
+            lv.off_conv2 = (int)b.size();
+            for (int v : nodes)
+                push_tile(b, h_slot(pl, v), -1, y_slot(pl, v), -1, in_slot(pl, v), -1, -1,
+                          pl->nodes[v].token);
+        }
+        if (pl->has_fused) {
+            // the same passes as one fused tile per node (vqa_resblock_tile, 12 words):
+            // [children -> P] -> H -> Y
+            lv.off_fused_fwd = (int)b.size();
+            for (int v : nodes) {
+                const PlanNode& nd = pl->nodes[v];
+                const int in = in_slot(pl, v);
+                const bool bin = nd.child1 >= 0;
+                const int32_t w[12] = {bin ? y_slot(pl, nd.child0) : in, bin ? y_slot(pl, nd.child1) : -1,
+                                       y_slot(pl, v), h_slot(pl, v), in, -1, -1, nd.token, -1, -1, -1, -1};
+                b.insert(b.end(), w, w + 12);
+            }
+        }
+    }
+    pl->max_level_tiles = max_tiles;
+    auto sec = [&](int id) { pl->sec_off[id] = (int)b.size(); };
+    auto endsec = [&](int id, int count) { pl->sec_cnt[id] = count; };
+    sec(VQA_SEC_STEM0_TILES);
+    for (int i = 0; i < M; i++) push_tile(b, i, -1, pl->slot_S0 + i, -1, -1, -1, -1, 0);
+    endsec(VQA_SEC_STEM0_TILES, M);
+    sec(VQA_SEC_STEM1_TILES);
+    for (int i = 0; i < M; i++) push_tile(b, pl->slot_S0 + i, -1, pl->slot_F + i, -1, -1, -1, -1, 0);
+    endsec(VQA_SEC_STEM1_TILES, M);
+    sec(VQA_SEC_CLS_FWD_TILES);
+    for (int i = 0; i < N; i++) push_tile(b, y_slot(pl, pl->roots[i]), -1, i, -1, -1, -1, -1, 0);
+    endsec(VQA_SEC_CLS_FWD_TILES, N);
+}
+
+// Backward half: input-gradient tile lists per level, per-sample sections, weight-gradient work
+// items.  Appended behind the forward half; nothing written earlier moves.
+void build_backward_part(vqa_plan* pl) {
+    std::vector<int32_t>& b = pl->blob;
+    const int N = pl->N, NV = (int)pl->nodes.size(), V = pl->V, wgrad_chunk = pl->wgrad_chunk;
+    const int scene_id = pl->scene_id;
+    pl->finished = true;
+    for (int L = 0; L < pl->num_levels; L++) {
+        PlanLevel& lv = pl->levels[L];
+        const std::vector<int>& nodes = pl->level_nodes[L];
+        auto target = [&](int v, int& dst, int& mask) {
+            // d(input) lands masked by (input > 0): a scene node's input is the image's stem map
+            const PlanNode& nd = pl->nodes[v];
+            if (nd.token == scene_id) { dst = pl->slot_dF + nd.sample; mask = pl->slot_F + nd.sample; }
+            else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
+            else { dst = pl->slot_dZ + nd.child0; mask = y_slot(pl, nd.child0); }
+        };
+        if (pl->has_separate) {
+            // dH = dgrad_conv2(dZ) * (H > 0)
+            lv.off_dgrad2 = (int)b.size();
+            for (int v : nodes)
+                push_tile(b, pl->slot_dZ + v, -1, dh_slot(pl, v), -1, -1, h_slot(pl, v), -1, pl->nodes[v].token);
+            // d(input) = (dgrad_conv1(dH) + dZ) * (input > 0)
+            lv.off_dgrad1 = (int)b.size();
+            for (int v : nodes) {
+                int dst, mask;
+                target(v, dst, mask);
+                push_tile(b, dh_slot(pl, v), -1, dst, -1, pl->slot_dZ + v, mask, -1, pl->nodes[v].token);
+            }
+            lv.off_dproj = (int)b.size();
+            for (int v : nodes) {
+                const PlanNode& nd = pl->nodes[v];
+                if (nd.child1 < 0) continue;
+                push_tile(b, pl->slot_dP + pl->bin_index[v], -1, pl->slot_dZ + nd.child0,
+                          pl->slot_dZ + nd.child1, -1, y_slot(pl, nd.child0), y_slot(pl, nd.child1), nd.token);
+            }
+        }
+        if (pl->has_fused) {   // dZ -> dH -> dX [-> children's dZ] as one tile
+            lv.off_fused_bwd = (int)b.size();
+            for (int v : nodes) {
+                const PlanNode& nd = pl->nodes[v];
+                int dst, mask;
+                target(v, dst, mask);
+                const bool bin = nd.child1 >= 0;
+                const int32_t w[12] = {pl->slot_dZ + v, -1, dst, dh_slot(pl, v), pl->slot_dZ + v, mask, h_slot(pl, v),
+                                       nd.token, bin ? pl->slot_dZ + nd.child0 : -1, bin ? pl->slot_dZ + nd.child1 : -1,
+                                       bin ? y_slot(pl, nd.child0) : -1, bin ? y_slot(pl, nd.child1) : -1};
+                b.insert(b.end(), w, w + 12);
+            }
+        }
+    }
+
+    auto sec = [&](int id) { pl->sec_off[id] = (int)b.size(); };
+    auto endsec = [&](int id, int count) { pl->sec_cnt[id] = count; };
+    sec(VQA_SEC_STEM1_DGRAD_TILES);
+    for (int i = 0; i < N; i++)
+        push_tile(b, pl->slot_dF + i, -1, pl->slot_dS0 + i, -1, -1, pl->slot_S0 + i, -1, 0);
+    endsec(VQA_SEC_STEM1_DGRAD_TILES, N);
+    sec(VQA_SEC_CLS_DGRAD_TILES);
+    for (int i = 0; i < N; i++)
+        push_tile(b, i, -1, pl->slot_dZ + pl->roots[i], -1, -1, y_slot(pl, pl->roots[i]), -1, 0);
+    endsec(VQA_SEC_CLS_DGRAD_TILES, N);
+
+    auto slot_list = [&](int id, int base_slot) {
+        sec(id);
+        for (int i = 0; i < N; i++) b.push_back(base_slot + i);
+        endsec(id, N);
+    };
+    slot_list(VQA_SEC_SLOTS_IDENT, 0);
+    slot_list(VQA_SEC_SLOTS_S0, pl->slot_S0);
+    slot_list(VQA_SEC_SLOTS_F, pl->slot_F);
+    slot_list(VQA_SEC_SLOTS_DF, pl->slot_dF);
+    slot_list(VQA_SEC_SLOTS_DS0, pl->slot_dS0);
+    sec(VQA_SEC_SLOTS_ROOTY);
+    for (int i = 0; i < N; i++) b.push_back(y_slot(pl, pl->roots[i]));
+    endsec(VQA_SEC_SLOTS_ROOTY, N);
+
+    // sample-chunk work items (one weight group) for the stem / classifier weight gradients
+    sec(VQA_SEC_SAMPLE_ITEMS);
+    int nitems = 0;
+    for (int s = 0; s < N; s += wgrad_chunk, nitems++) {
+        const int32_t it[4] = {0, s, std::min(wgrad_chunk, N - s), 0};
+        b.insert(b.end(), it, it + 4);
+    }
+    endsec(VQA_SEC_SAMPLE_ITEMS, nitems);
+    // the same in finer chunks (at least 128 items when N allows), for launches whose grid is
+    // items x 2 only (stem conv 2: 128 source channels) and would otherwise leave most CUs idle
+    sec(VQA_SEC_SAMPLE_ITEMS_FINE);
+    const int fine = std::max(1, std::min(wgrad_chunk, N / 128));
+    nitems = 0;
+    for (int s = 0; s < N; s += fine, nitems++) {
+        const int32_t it[4] = {0, s, std::min(fine, N - s), 0};
+        b.insert(b.end(), it, it + 4);
+    }
+    endsec(VQA_SEC_SAMPLE_ITEMS_FINE, nitems);
+
+    // scene fan-in (CSR by sample): the dZ slots of a sample's scene nodes (node order) ...
+    {
+        std::vector<int> cnt(N + 1, 0);
+        for (int v = 0; v < NV; v++) if (pl->scene_index[v] >= 0) cnt[pl->nodes[v].sample + 1]++;
+        for (int i = 0; i < N; i++) cnt[i + 1] += cnt[i];
+        sec(VQA_SEC_SCENE_OFFSETS);
+        b.insert(b.end(), cnt.begin(), cnt.end());
+        endsec(VQA_SEC_SCENE_OFFSETS, N + 1);
+        sec(VQA_SEC_SCENE_SRC);
+        const size_t at = b.size();
+        b.resize(at + cnt[N]);
+        for (int v = 0; v < NV; v++)
+            if (pl->scene_index[v] >= 0) b[at + cnt[pl->nodes[v].sample]++] = pl->slot_dZ + v;
+        endsec(VQA_SEC_SCENE_SRC, (int)(b.size() - at));
+    }
+    // ... summed into the representative's dZ slot, times (its output > 0)
+    sec(VQA_SEC_SLOTS_SCDZ);
+    for (int i = 0; i < N; i++) b.push_back(pl->slot_dZ + pl->first_scene[i]);
+    endsec(VQA_SEC_SLOTS_SCDZ, N);
+    sec(VQA_SEC_SLOTS_SCY);
+    for (int i = 0; i < N; i++) b.push_back(pl->slot_Ysc + i);
+    endsec(VQA_SEC_SLOTS_SCY, N);
+
+    // module weight gradients: nodes grouped by token, cut into items of <= wgrad_chunk nodes
+    std::vector<std::vector<int>> by_tok(V);
+    for (int v = 0; v < NV; v++) if (pl->rep[v] == v) by_tok[pl->nodes[v].token].push_back(v);
+    std::vector<int32_t> items, src_c1, dy_c1, src_c2, dy_c2;
+    std::vector<int32_t> pitems, psrc0, psrc1, pdy;
+    src_c1.reserve(NV); dy_c1.reserve(NV); src_c2.reserve(NV); dy_c2.reserve(NV);
+    for (int t = 0; t < V; t++) {
+        const std::vector<int>& vs = by_tok[t];
+        if (vs.empty()) continue;
+        for (size_t s = 0; s < vs.size(); s += wgrad_chunk) {
+            const int32_t it[4] = {t, (int32_t)src_c1.size(),
+                                   (int32_t)std::min<size_t>(wgrad_chunk, vs.size() - s), 0};
+            items.insert(items.end(), it, it + 4);
+            for (size_t k = s; k < s + it[2]; k++) {
+                int v = vs[k];
+                src_c1.push_back(in_slot(pl, v)); dy_c1.push_back(dh_slot(pl, v));
+                src_c2.push_back(h_slot(pl, v)); dy_c2.push_back(pl->slot_dZ + v);
+            }
+        }
+        if (pl->nodes[vs[0]].child1 >= 0) {
+            for (size_t s = 0; s < vs.size(); s += wgrad_chunk) {
+                const int32_t it[4] = {t, (int32_t)psrc0.size(),
+                                       (int32_t)std::min<size_t>(wgrad_chunk, vs.size() - s), 0};
+                pitems.insert(pitems.end(), it, it + 4);
+                for (size_t k = s; k < s + it[2]; k++) {
+                    int v = vs[k];
+                    psrc0.push_back(y_slot(pl, pl->nodes[v].child0));
+                    psrc1.push_back(y_slot(pl, pl->nodes[v].child1));
+                    pdy.push_back(pl->slot_dP + pl->bin_index[v]);
+                }
+            }
+        }
+    }
+    // longest items first: workgroups are dispatched in index order as CUs free up, so this is the
+    // greedy longest-processing-time schedule and the launch does not end on a late long item
+    auto by_count = [](std::vector<int32_t>& its) {
+        struct It { int32_t w[4]; };
+        It* a = reinterpret_cast<It*>(its.data());
+        std::stable_sort(a, a + its.size() / 4, [](const It& x, const It& y) { return x.w[2] > y.w[2]; });
+    };
+    by_count(items);
+    by_count(pitems);
+    auto put = [&](int id, const std::vector<int32_t>& v, int count) {
+        sec(id); b.insert(b.end(), v.begin(), v.end()); endsec(id, count);
+    };
+    put(VQA_SEC_WG_ITEMS, items, (int)items.size() / 4);
+    put(VQA_SEC_WG_SRC_C1, src_c1, (int)src_c1.size());
+    put(VQA_SEC_WG_DY_C1, dy_c1, (int)dy_c1.size());
+    put(VQA_SEC_WG_SRC_C2, src_c2, (int)src_c2.size());
+    put(VQA_SEC_WG_DY_C2, dy_c2, (int)dy_c2.size());
+    put(VQA_SEC_WG_PITEMS, pitems, (int)pitems.size() / 4);
+    put(VQA_SEC_WG_PSRC0, psrc0, (int)psrc0.size());
+    put(VQA_SEC_WG_PSRC1, psrc1, (int)psrc1.size());
+    put(VQA_SEC_WG_PDY, pdy, (int)pdy.size());
 }
 
 }  // namespace
@@ -207,21 +506,22 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
             return VQA_EINVAL;
         }
     }
-    vqa_plan* pl = new (std::nothrow) vqa_plan();
+    vqa_plan* pl = plan_acquire();
     if (!pl) { vqa_set_error("out of host memory"); return VQA_EINVAL; }
     pl->N = N; pl->T = T; pl->C = C; pl->V = V;
     pl->M = num_images; pl->shared = image_of_sample != nullptr;
     pl->used.assign((size_t)N * T, 0.0f);
     pl->nodes.reserve((size_t)N * (T + 1));
     pl->roots.reserve(N);
+    std::vector<Frame> stack;
+    stack.reserve(2 * T + 2);
     for (int i = 0; i < N; i++) {
         pl->pending.clear();
         int rc = parse_row(programs + (size_t)i * T, T, arity, V, null_id, start_id, scene_id, i,
-                           image_of_sample ? image_of_sample[i] : i, pl, pl->used.data() + (size_t)i * T);
-        if (rc) { delete pl; return rc; }
+                           image_of_sample ? image_of_sample[i] : i, pl, pl->used.data() + (size_t)i * T, stack);
+        if (rc) { plan_release(pl); return rc; }
     }
     pl->pending.clear();
-    pl->pending.shrink_to_fit();
     pl->interned.clear();
     const int M = pl->M;
 
@@ -267,12 +567,10 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     pl->slot_dP = pl->slot_dHsc + M;
     pl->slot_dFp = 0; pl->slot_dF = pl->slot_dP + nb; pl->slot_dS0 = pl->slot_dF + M;
     pl->slots_total = pl->shared ? pl->slots_fwd : pl->slot_dS0 + M;
-    auto y_slot = [&](int v) { return pl->nodes[v].token == scene_id ? pl->slot_Ysc + pl->nodes[v].sample : pl->slot_Y + v; };
-    auto h_slot = [&](int v) { return pl->nodes[v].token == scene_id ? pl->slot_Hsc + pl->nodes[v].sample : pl->slot_H + v; };
-    auto dh_slot = [&](int v) { return pl->nodes[v].token == scene_id ? pl->slot_dHsc + pl->nodes[v].sample : pl->slot_dH + v; };
+    pl->scene_id = scene_id; pl->wgrad_chunk = wgrad_chunk; pl->flags = flags;
 
     // level buckets: nodes of a level sorted by (token, node id)
-    pl->level_nodes.assign(pl->num_levels, {});
+    if ((int)pl->level_nodes.size() < pl->num_levels) pl->level_nodes.resize(pl->num_levels);
     {
         std::vector<int> cnt(pl->num_levels, 0);
         for (int v = 0; v < NV; v++) if (pl->rep[v] == v) cnt[pl->nodes[v].level]++;
@@ -290,237 +588,27 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
             lv.swap(tmp);
         }
     }
-
-    auto in_slot = [&](int v) {   // slot the residual body of node v reads
-        const PlanNode& nd = pl->nodes[v];
-        if (nd.token == scene_id) return pl->slot_F + nd.sample;
-        if (nd.child1 >= 0) return pl->slot_P + pl->bin_index[v];
-        return y_slot(nd.child0);
-    };
-
-    std::vector<int32_t>& b = pl->blob;
-    b.reserve((size_t)NV * 80 + (size_t)N * 64 + (size_t)nb * 24 + 1024);
-    pl->levels.assign(pl->num_levels, {});
-    int max_tiles = 0;
-    for (int L = 0; L < pl->num_levels; L++) {
-        PlanLevel& lv = pl->levels[L];
-        const std::vector<int>& nodes = pl->level_nodes[L];
-        lv.count = (int)nodes.size();
-        max_tiles = std::max(max_tiles, lv.count);
-        // binary nodes of the level keep the same (token, id) order
-        std::vector<int> bins;
-        for (int v : nodes) if (pl->nodes[v].child1 >= 0) bins.push_back(v);
-        lv.bcount = (int)bins.size();
-        if (!(flags & VQA_PLAN_SKIP_SEPARATE)) {   // one tile list per convolution pass
-            lv.off_proj = (int)b.size();
-            for (int v : bins) {
-                const PlanNode& nd = pl->nodes[v];
-                push_tile(b, y_slot(nd.child0), y_slot(nd.child1),
-                          pl->slot_P + pl->bin_index[v], -1, -1, -1, -1, nd.token);
-            }
-            lv.off_conv1 = (int)b.size();
-            for (int v : nodes)
-                push_tile(b, in_slot(v), -1, h_slot(v), -1, -1, -1, -1, pl->nodes[v].token);
-            lv.off_conv2 = (int)b.size();
-            for (int v : nodes)
-                push_tile(b, h_slot(v), -1, y_slot(v), -1, in_slot(v), -1, -1,
-                          pl->nodes[v].token);
-            // backward: dH = dgrad_conv2(dZ) * (H > 0)
-            lv.off_dgrad2 = (int)b.size();
-            if (!pl->shared) for (int v : nodes)
-                push_tile(b, pl->slot_dZ + v, -1, dh_slot(v), -1, -1, h_slot(v), -1,
-                          pl->nodes[v].token);
-            // d(input) = (dgrad_conv1(dH) + dZ) * (input > 0); a scene node's input is the shared
-            // stem map, so its gradient goes unmasked to a per-node slot and is summed later
-            lv.off_dgrad1 = (int)b.size();
-            if (!pl->shared) for (int v : nodes) {
-                const PlanNode& nd = pl->nodes[v];
-                int dst, mask;
-                if (nd.token == scene_id) { dst = pl->slot_dF + nd.sample; mask = pl->slot_F + nd.sample; }
-                else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
-                else { dst = pl->slot_dZ + nd.child0; mask = y_slot(nd.child0); }
-                push_tile(b, dh_slot(v), -1, dst, -1, pl->slot_dZ + v, mask, -1, nd.token);
-            }
-        }
-        if (!(flags & VQA_PLAN_SKIP_SEPARATE)) {
-            lv.off_dproj = (int)b.size();
-            if (!pl->shared) for (int v : bins) {
-                const PlanNode& nd = pl->nodes[v];
-                push_tile(b, pl->slot_dP + pl->bin_index[v], -1, pl->slot_dZ + nd.child0,
-                          pl->slot_dZ + nd.child1, -1, y_slot(nd.child0), y_slot(nd.child1),
-                          nd.token);
-            }
-        }
-        if (!(flags & VQA_PLAN_SKIP_FUSED)) {
-            // the same passes as two fused tiles per node (vqa_resblock_tile, 12 words): forward
-            // ([children -> P] -> H -> Y) and backward (dZ -> dH -> dX [-> children's dZ])
-            lv.off_fused_fwd = (int)b.size();
-            for (int v : nodes) {
-                const PlanNode& nd = pl->nodes[v];
-                const int in = in_slot(v);
-                const bool bin = nd.child1 >= 0;
-                const int32_t w[12] = {bin ? y_slot(nd.child0) : in, bin ? y_slot(nd.child1) : -1,
-                                       y_slot(v), h_slot(v), in, -1, -1, nd.token, -1, -1, -1, -1};
-                b.insert(b.end(), w, w + 12);
-            }
-            lv.off_fused_bwd = (int)b.size();
-            if (!pl->shared) for (int v : nodes) {
-                const PlanNode& nd = pl->nodes[v];
-                int dst, mask;
-                if (nd.token == scene_id) { dst = pl->slot_dF + nd.sample; mask = pl->slot_F + nd.sample; }
-                else if (nd.child1 >= 0) { dst = pl->slot_dP + pl->bin_index[v]; mask = pl->slot_P + pl->bin_index[v]; }
-                else { dst = pl->slot_dZ + nd.child0; mask = y_slot(nd.child0); }
-                const bool bin = nd.child1 >= 0;
-                const int32_t w[12] = {pl->slot_dZ + v, -1, dst, dh_slot(v), pl->slot_dZ + v, mask, h_slot(v), nd.token,
-                                       bin ? pl->slot_dZ + nd.child0 : -1, bin ? pl->slot_dZ + nd.child1 : -1,
-                                       bin ? y_slot(nd.child0) : -1, bin ? y_slot(nd.child1) : -1};
-                b.insert(b.end(), w, w + 12);
-            }
-        }
-    }
-    pl->max_level_tiles = max_tiles;
     pl->has_separate = !(flags & VQA_PLAN_SKIP_SEPARATE);
     pl->has_fused = !(flags & VQA_PLAN_SKIP_FUSED);
-
-    // per-sample sections
-    auto sec = [&](int id) { pl->sec_off[id] = (int)b.size(); };
-    auto endsec = [&](int id, int count) { pl->sec_cnt[id] = count; };
-    sec(VQA_SEC_STEM0_TILES);
-    for (int i = 0; i < M; i++) push_tile(b, i, -1, pl->slot_S0 + i, -1, -1, -1, -1, 0);
-    endsec(VQA_SEC_STEM0_TILES, M);
-    sec(VQA_SEC_STEM1_TILES);
-    for (int i = 0; i < M; i++) push_tile(b, pl->slot_S0 + i, -1, pl->slot_F + i, -1, -1, -1, -1, 0);
-    endsec(VQA_SEC_STEM1_TILES, M);
-    sec(VQA_SEC_STEM1_DGRAD_TILES);
-    if (!pl->shared)
-        for (int i = 0; i < N; i++)
-            push_tile(b, pl->slot_dF + i, -1, pl->slot_dS0 + i, -1, -1, pl->slot_S0 + i, -1, 0);
-    endsec(VQA_SEC_STEM1_DGRAD_TILES, pl->shared ? 0 : N);
-    sec(VQA_SEC_CLS_FWD_TILES);
-    for (int i = 0; i < N; i++) push_tile(b, y_slot(pl->roots[i]), -1, i, -1, -1, -1, -1, 0);
-    endsec(VQA_SEC_CLS_FWD_TILES, N);
-    if (pl->shared) {      // forward only: no backward sections (their counts stay zero)
-        if (b.empty()) b.push_back(0);
-        *out = pl;
-        return VQA_OK;
-    }
-    sec(VQA_SEC_CLS_DGRAD_TILES);
-    for (int i = 0; i < N; i++)
-        push_tile(b, i, -1, pl->slot_dZ + pl->roots[i], -1, -1, y_slot(pl->roots[i]), -1, 0);
-    endsec(VQA_SEC_CLS_DGRAD_TILES, N);
-
-    auto slot_list = [&](int id, int base_slot) {
-        sec(id);
-        for (int i = 0; i < N; i++) b.push_back(base_slot + i);
-        endsec(id, N);
-    };
-    slot_list(VQA_SEC_SLOTS_IDENT, 0);
-    slot_list(VQA_SEC_SLOTS_S0, pl->slot_S0);
-    slot_list(VQA_SEC_SLOTS_F, pl->slot_F);
-    slot_list(VQA_SEC_SLOTS_DF, pl->slot_dF);
-    slot_list(VQA_SEC_SLOTS_DS0, pl->slot_dS0);
-    sec(VQA_SEC_SLOTS_ROOTY);
-    for (int i = 0; i < N; i++) b.push_back(y_slot(pl->roots[i]));
-    endsec(VQA_SEC_SLOTS_ROOTY, N);
-
-    // sample-chunk work items (one weight group) for the stem / classifier weight gradients
-    sec(VQA_SEC_SAMPLE_ITEMS);
-    int nitems = 0;
-    for (int s = 0; s < N; s += wgrad_chunk, nitems++) {
-        const int32_t it[4] = {0, s, std::min(wgrad_chunk, N - s), 0};
-        b.insert(b.end(), it, it + 4);
-    }
-    endsec(VQA_SEC_SAMPLE_ITEMS, nitems);
-    // the same in finer chunks (at least 128 items when N allows), for launches whose grid is
-    // items x 2 only (stem conv 2: 128 source channels) and would otherwise leave most CUs idle
-    sec(VQA_SEC_SAMPLE_ITEMS_FINE);
-    const int fine = std::max(1, std::min(wgrad_chunk, N / 128));
-    nitems = 0;
-    for (int s = 0; s < N; s += fine, nitems++) {
-        const int32_t it[4] = {0, s, std::min(fine, N - s), 0};
-        b.insert(b.end(), it, it + 4);
-    }
-    endsec(VQA_SEC_SAMPLE_ITEMS_FINE, nitems);
-
-    // scene fan-in (CSR by sample)
-    std::vector<std::vector<int>> scenes(N);
-    for (int v = 0; v < NV; v++)
-        if (pl->scene_index[v] >= 0) scenes[pl->nodes[v].sample].push_back(pl->slot_dZ + v);
-    sec(VQA_SEC_SCENE_OFFSETS);
-    int run = 0;
-    for (int i = 0; i < N; i++) { b.push_back(run); run += (int)scenes[i].size(); }
-    b.push_back(run);
-    endsec(VQA_SEC_SCENE_OFFSETS, N + 1);
-    sec(VQA_SEC_SCENE_SRC);
-    for (int i = 0; i < N; i++) for (int s : scenes[i]) b.push_back(s);
-    endsec(VQA_SEC_SCENE_SRC, run);
-    // ... summed into the representative's dZ slot, times (its output > 0)
-    sec(VQA_SEC_SLOTS_SCDZ);
-    for (int i = 0; i < N; i++) b.push_back(pl->slot_dZ + pl->first_scene[i]);
-    endsec(VQA_SEC_SLOTS_SCDZ, N);
-    sec(VQA_SEC_SLOTS_SCY);
-    for (int i = 0; i < N; i++) b.push_back(pl->slot_Ysc + i);
-    endsec(VQA_SEC_SLOTS_SCY, N);
-
-    // module weight gradients: nodes grouped by token, cut into items of <= wgrad_chunk nodes
-    std::vector<std::vector<int>> by_tok(V);
-    for (int v = 0; v < NV; v++) if (pl->rep[v] == v) by_tok[pl->nodes[v].token].push_back(v);
-    std::vector<int32_t> items, src_c1, dy_c1, src_c2, dy_c2;
-    std::vector<int32_t> pitems, psrc0, psrc1, pdy;
-    for (int t = 0; t < V; t++) {
-        const std::vector<int>& vs = by_tok[t];
-        if (vs.empty()) continue;
-        for (size_t s = 0; s < vs.size(); s += wgrad_chunk) {
-            const int32_t it[4] = {t, (int32_t)src_c1.size(),
-                                   (int32_t)std::min<size_t>(wgrad_chunk, vs.size() - s), 0};
-            items.insert(items.end(), it, it + 4);
-            for (size_t k = s; k < s + it[2]; k++) {
-                int v = vs[k];
-                src_c1.push_back(in_slot(v)); dy_c1.push_back(dh_slot(v));
-                src_c2.push_back(h_slot(v)); dy_c2.push_back(pl->slot_dZ + v);
-            }
-        }
-        if (pl->nodes[vs[0]].child1 >= 0) {
-            for (size_t s = 0; s < vs.size(); s += wgrad_chunk) {
-                const int32_t it[4] = {t, (int32_t)psrc0.size(),
-                                       (int32_t)std::min<size_t>(wgrad_chunk, vs.size() - s), 0};
-                pitems.insert(pitems.end(), it, it + 4);
-                for (size_t k = s; k < s + it[2]; k++) {
-                    int v = vs[k];
-                    psrc0.push_back(y_slot(pl->nodes[v].child0));
-                    psrc1.push_back(y_slot(pl->nodes[v].child1));
-                    pdy.push_back(pl->slot_dP + pl->bin_index[v]);
-                }
-            }
-        }
-    }
-    // longest items first: workgroups are dispatched in index order as CUs free up, so this is the
-    // greedy longest-processing-time schedule and the launch does not end on a late long item
-    auto by_count = [](std::vector<int32_t>& its) {
-        struct It { int32_t w[4]; };
-        It* a = reinterpret_cast<It*>(its.data());
-        std::stable_sort(a, a + its.size() / 4, [](const It& x, const It& y) { return x.w[2] > y.w[2]; });
-    };
-    by_count(items);
-    by_count(pitems);
-    auto put = [&](int id, const std::vector<int32_t>& v, int count) {
-        sec(id); b.insert(b.end(), v.begin(), v.end()); endsec(id, count);
-    };
-    put(VQA_SEC_WG_ITEMS, items, (int)items.size() / 4);
-    put(VQA_SEC_WG_SRC_C1, src_c1, (int)src_c1.size());
-    put(VQA_SEC_WG_DY_C1, dy_c1, (int)dy_c1.size());
-    put(VQA_SEC_WG_SRC_C2, src_c2, (int)src_c2.size());
-    put(VQA_SEC_WG_DY_C2, dy_c2, (int)dy_c2.size());
-    put(VQA_SEC_WG_PITEMS, pitems, (int)pitems.size() / 4);
-    put(VQA_SEC_WG_PSRC0, psrc0, (int)psrc0.size());
-    put(VQA_SEC_WG_PSRC1, psrc1, (int)psrc1.size());
-    put(VQA_SEC_WG_PDY, pdy, (int)pdy.size());
-    if (b.empty()) b.push_back(0);
+    // upper bound of the finished blob, so that a caller can size its buffers after the forward part
+    pl->blob_bound = (size_t)NV * 80 + (size_t)N * 64 + (size_t)nb * 24 + (size_t)V * 16 + 1024;
+    pl->blob.reserve(pl->blob_bound);
+    build_forward_part(pl);
+    pl->fwd_words = (int)pl->blob.size();
+    pl->finished = pl->shared;      // forward-only plans have no backward part
+    if (!pl->shared && !(flags & VQA_PLAN_DEFER_BACKWARD)) build_backward_part(pl);
+    if (pl->blob.empty()) pl->blob.push_back(0);
     *out = pl;
     return VQA_OK;
 }
 
-extern "C" void vqa_plan_free(vqa_plan* plan) { delete plan; }
+extern "C" int vqa_plan_finish(vqa_plan* pl) {
+    if (!pl) { vqa_set_error("null plan"); return VQA_EINVAL; }
+    if (!pl->finished) build_backward_part(pl);
+    return VQA_OK;
+}
+
+extern "C" void vqa_plan_free(vqa_plan* plan) { plan_release(plan); }
 
 extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
     if (!pl || !o) { vqa_set_error("null plan"); return VQA_EINVAL; }
@@ -535,6 +623,8 @@ extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
     o->max_level_tiles = pl->max_level_tiles;
     o->num_images = pl->M;
     o->num_exec_nodes = pl->num_exec;
+    o->blob_fwd_words = pl->fwd_words;
+    o->blob_words_bound = (int)pl->blob_bound;
     {   // one block of 8192 floats per tap and workgroup of the largest weight-gradient launch
         const int cc = pl->C / 128, os = pl->C / 64;
         o->wgrad_partial_blocks = std::max(pl->sec_cnt[VQA_SEC_WG_ITEMS] * os * cc * 9,
@@ -575,6 +665,15 @@ extern "C" int vqa_plan_token_counts(const vqa_plan* pl, int32_t* out) {
 extern "C" int vqa_plan_roots(const vqa_plan* pl, int32_t* out) {
     if (!pl || !out) { vqa_set_error("null argument"); return VQA_EINVAL; }
     std::memcpy(out, pl->roots.data(), pl->roots.size() * sizeof(int32_t));
+    return VQA_OK;
+}
+
+extern "C" int vqa_plan_blob_range(const vqa_plan* pl, int32_t first, int32_t count, int32_t* out) {
+    if (!pl || !out || first < 0 || count < 0 || (size_t)first + (size_t)count > pl->blob.size()) {
+        vqa_set_error("vqa_plan_blob_range: bad argument");
+        return VQA_EINVAL;
+    }
+    std::memcpy(out, pl->blob.data() + first, (size_t)count * sizeof(int32_t));
     return VQA_OK;
 }
 

@@ -94,6 +94,10 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
         vqa_set_error("vqa_tree_backward: a plan built with shared images is forward-only");
         return VQA_EINVAL;
     }
+    if (!pl->finished) {
+        vqa_set_error("vqa_tree_backward: the plan's backward part is not built yet (vqa_plan_finish)");
+        return VQA_EINVAL;
+    }
     const int cc = pl->C / 128;
     const int64_t w33 = (int64_t)9 * pl->C * pl->C, w11 = (int64_t)2 * pl->C * pl->C;
     const int64_t slot = (int64_t)VQA_HW * pl->C;

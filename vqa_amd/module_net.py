@@ -502,23 +502,25 @@ class ModuleNet(nn.Module):
                 arrived.synchronize()
             plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk,
                         (_lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED) |
-                        (_lib.PLAN_BALANCE if self.balance_levels else 0),
+                        (_lib.PLAN_BALANCE if self.balance_levels else 0) | _lib.PLAN_DEFER_BACKWARD,
                         image_index=image_index, num_images=M if image_index is not None else None)
             st['plan'] = plan
             info = plan.info
             self.last_token_counts = plan.token_counts()
-            nb = info.blob_words
+            # the forward part of the tile lists goes up now; the backward part is written and sent
+            # once the forward launches are enqueued (the host is what the device waits for here)
+            nb, bound = info.blob_words, info.blob_words_bound
             host = ws.bufs.get('blob_host')
-            if host is None or host.numel() < nb:
-                host = ws.bufs['blob_host'] = torch.empty(nb + nb // 4, dtype=torch.int32, pin_memory=True)
-            plan.blob_into(host)
+            if host is None or host.numel() < bound:
+                host = ws.bufs['blob_host'] = torch.empty(bound + bound // 4, dtype=torch.int32, pin_memory=True)
+            plan.blob_range_into(host, 0, nb)
             hused = hp[:(N * T + 1) // 2].view(torch.float32)[:N * T].view(N, T)   # programs are parsed: reuse
             plan.used_fns_into(hused)
-            st['blob'] = ws.get('blob', nb, torch.int32, dev)
+            st['blob'] = ws.get('blob', bound, torch.int32, dev)
             # Module_Model.py:227,231: a float tensor on the program's device
             used = torch.empty(N, T, dtype=torch.float32, device=program.device)
             with torch.cuda.stream(side):
-                st['blob'].copy_(host[:nb], non_blocking=True)
+                st['blob'][:nb].copy_(host[:nb], non_blocking=True)
                 if used.is_cuda:
                     used.copy_(hused, non_blocking=True)
                     used.record_stream(side)
@@ -572,6 +574,15 @@ class ModuleNet(nn.Module):
                 acts.append(a)
                 prev_dim = fo
         st['acts'] = acts
+        if need_grad:
+            plan.finish()
+            total = plan.info.blob_words
+            plan.blob_range_into(host, nb, total - nb)
+            with torch.cuda.stream(side):
+                st['blob'][nb:total].copy_(host[nb:total], non_blocking=True)
+                ws.host_event = torch.cuda.Event()
+                ws.host_event.record(side)
+            st['blob_ready'] = ws.host_event
         if self.keep_state:
             self.last_state = st
         return st
@@ -778,6 +789,7 @@ class ModuleNet(nn.Module):
         plan, pk, N = st['plan'], st['pk'], st['N']
         dev = dlogits.device
         ws, lib = st['ws'], _lib.load()
+        torch.cuda.current_stream(dev).wait_event(st['blob_ready'])     # backward half of the tile lists
         c, p_, cpad, nv = d['c'], d['p'], d['cin_pad'], len(self._tokens)
         np128, np64 = _rup(N, 128), _rup(N, 64)
         arena, blob, acts = st['arena'], st['blob'], st['acts']

@@ -97,6 +97,17 @@ class Plan:
         assert host_tensor.numel() >= self.info.blob_words
         _lib.check(self._lib.vqa_plan_blob(self._h, C.cast(host_tensor.data_ptr(), _lib.i32p)))
 
+    def finish(self):
+        """Builds the backward part of a plan made with PLAN_DEFER_BACKWARD and refreshes `info`."""
+        _lib.check(self._lib.vqa_plan_finish(self._h))
+        _lib.check(self._lib.vqa_plan_get_info(self._h, C.byref(self.info)))
+
+    def blob_range_into(self, host_tensor, first, count):
+        """Words [first, first + count) of the blob into the same positions of an int32 host tensor."""
+        assert host_tensor.numel() >= first + count and host_tensor.dtype.itemsize == 4
+        _lib.check(self._lib.vqa_plan_blob_range(self._h, first, count,
+                                                 C.cast(host_tensor.data_ptr() + 4 * first, _lib.i32p)))
+
     def section(self, name):
         off, cnt = C.c_int32(), C.c_int32()
         _lib.check(self._lib.vqa_plan_section(self._h, _lib.SEC[name], C.byref(off), C.byref(cnt)))
