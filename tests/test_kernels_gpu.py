@@ -371,6 +371,33 @@ def test_gemm_tn(M, N, K):
     close(c.cpu(), a.t() @ b, 2e-3)
 
 
+def test_gemm_large_tiles_all_layouts():
+    """Problems with M, N multiples of 256 and at least 128 tiles take the 256 x 256-tile kernel:
+    the four operand layouts, split-k fp32 slabs, and the masked bf16 result."""
+    from vqa_amd import ops
+    M, N, K = 512, 16384, 192
+    a, b = bf(rnd((M, K), 50)) * 0.25, bf(rnd((N, K), 51)) * 0.25
+    ref = a @ b.t()
+    ad, bd = a.to(torch.bfloat16).to(dev()), b.to(torch.bfloat16).to(dev())
+    at, bt = ad.t().contiguous(), bd.t().contiguous()
+    for akm, bkm in ((False, False), (False, True), (True, True), (True, False)):
+        c = torch.full((M, N), 7.0, device=dev())
+        ops.gemm(at if akm else ad, bt if bkm else bd, c, M, N, K, lda=M if akm else K, ldb=N if bkm else K,
+                 ldc=N, a_kmajor=akm, b_kmajor=bkm)
+        torch.cuda.synchronize()
+        close(c.cpu(), ref, 2e-3)
+    c = torch.full((3, M, N), 7.0, device=dev())
+    ops.gemm(ad, bd, c, M, N, K, lda=K, ldb=K, ldc=N, split_k=3)
+    torch.cuda.synchronize()
+    close(c.sum(0).cpu(), ref, 2e-3)
+    mk = bf(F.relu(rnd((M, N), 52)))
+    cb = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(ad, bt, cb, M, N, K, lda=K, ldb=N, ldc=N, b_kmajor=True, out_bf16=True,
+             mask=mk.to(torch.bfloat16).to(dev()))
+    torch.cuda.synchronize()
+    close(cb.to(torch.float32).cpu(), ref * (mk > 0))
+
+
 def test_layout_helpers():
     from vqa_amd import ops
     n, cin, cpad = 3, 100, 128

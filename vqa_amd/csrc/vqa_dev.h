@@ -8,6 +8,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA 16x16x3
 typedef __attribute__((ext_vector_type(4))) float f32x4;     // one MFMA 16x16 C/D fragment
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) uint16_t u16x4;
+typedef __attribute__((ext_vector_type(8))) uint16_t u16x8;
 
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
