@@ -36,6 +36,11 @@ def test_fused_adam_matches_torch_adam(vocab):
         oa.step()
         ob.step()
     torch.cuda.synchronize()
+    # step counts live on the host between steps; reading the state (state_dict) writes them into
+    # the `step` tensors of torch's Adam state layout, which torch's own Adam can then load
+    sd_a = oa.state_dict()
+    assert sd_a['state'].keys() == ob.state_dict()['state'].keys()
+    torch.optim.Adam(a.parameters(), lr=1e-3).load_state_dict(sd_a)
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         err = (pa - pb).abs().max().item()
         assert err <= 2e-6 * max(1.0, pb.abs().max().item()), (k, err)

@@ -8,6 +8,7 @@ they are never called.  There is no CPU or eager-torch fallback: a CPU tensor or
 library raises.
 """
 import os
+import time
 import ctypes as C
 
 import numpy as np
@@ -208,8 +209,11 @@ class ModuleNet(nn.Module):
         self._stem_tile_cache = {}
         self._packed_key = None
         self._packed_stale = False
+        self._plist = None            # cached _param_groups()
+        self._stacks = None           # the per-token parameters' shared [V, ...] arrays
         self._packed = {}
         self._fc1_packed = None       # persistent bf16 copy of the first linear layer's weight
+        self.segment_marks = None     # diagnostics: see _mark
         self._fc1_fresh = False       # set by vqa_amd.optim.FusedAdam: that copy already holds the updated weight
         self.used_fns = None
         self.wgrad_chunk = 32
@@ -231,6 +235,8 @@ class ModuleNet(nn.Module):
     # ------------------------------------------------------------------ parameters
     def _param_groups(self):
         """Ordered (name, parameter) list handed to the autograd function."""
+        if self._plist is not None:
+            return self._plist
         out = [('stem.0', self.stem[0]), ('stem.2', self.stem[2]), ('classifier.0', self.classifier[0])]
         out += [('classifier.%d' % i, self.classifier[i]) for i in self._fc_idx]
         plist = []
@@ -242,15 +248,57 @@ class ModuleNet(nn.Module):
                 plist += [(tok + '.proj.weight', m.proj.weight), (tok + '.proj.bias', m.proj.bias)]
             plist += [(tok + '.conv1.weight', m.conv1.weight), (tok + '.conv1.bias', m.conv1.bias),
                       (tok + '.conv2.weight', m.conv2.weight), (tok + '.conv2.bias', m.conv2.bias)]
+        self._plist = plist
         return plist
+
+    def _apply(self, fn, *args, **kwargs):
+        # .cuda() / .to() / .float(): parameters get new storage; everything derived from it is rebuilt
+        out = super()._apply(fn, *args, **kwargs)
+        self._plist, self._stacks, self._packed_key = None, None, None
+        return out
+
+    def _stack_module_params(self, device):
+        """The per-token modules' parameters as rows of six [V, ...] device arrays (one weight group
+        per token, zeros where a token has no such parameter): each nn.Parameter's storage is moved
+        into its row, so the arrays ARE the parameters - an optimizer's in-place update, copy_() and
+        load_state_dict() write through - and the packing kernels read all tokens of a kind in one
+        launch without gathering them first.  Redone when the parameters were given new storage."""
+        d = self._dims
+        c, nv = d['c'], len(self._tokens)
+        f32 = dict(dtype=torch.float32, device=device)
+        st = {'device': device,
+              'w1': torch.zeros(nv, c, c, 3, 3, **f32), 'w2': torch.zeros(nv, c, c, 3, 3, **f32),
+              'wp': torch.zeros(nv, c, 2 * c, 1, 1, **f32),
+              'b1': torch.zeros(nv, c, **f32), 'b2': torch.zeros(nv, c, **f32), 'bp': torch.zeros(nv, c, **f32)}
+        with torch.no_grad():
+            for i, t in enumerate(self._tokens):
+                m = self._modules[t]
+                pairs = [(m.conv1.weight, st['w1']), (m.conv1.bias, st['b1']),
+                         (m.conv2.weight, st['w2']), (m.conv2.bias, st['b2'])]
+                if self._binary[i]:
+                    pairs += [(m.proj.weight, st['wp']), (m.proj.bias, st['bp'])]
+                for prm, arr in pairs:
+                    if prm.device != device or prm.dtype != torch.float32:
+                        raise RuntimeError('vqa_amd.ModuleNet: parameters must be fp32 tensors on the features\' device')
+                    arr[i].copy_(prm.detach())
+                    prm.data = arr[i]
+        nfixed = 2 * (3 + len(self._fc_idx))        # stem, classifier conv and linear layers come first
+        st['sig'] = tuple(p.data_ptr() for _, p in self._param_groups()[nfixed:])
+        self._stacks = st
+        return st
 
     def _pack_weights(self, device):
         """bf16 LDS-image copies of all weights; redone only when a parameter changed."""
         plist = self._param_groups()
+        ptrs = tuple(p.data_ptr() for _, p in plist)
+        stk = self._stacks
+        if stk is None or stk['device'] != device or ptrs[len(ptrs) - len(stk['sig']):] != stk['sig']:
+            stk = self._stack_module_params(device)          # moves the per-token parameters
+            ptrs = tuple(p.data_ptr() for _, p in plist)
         # Version counters catch in-place edits and load_state_dict, but torch's fused optimizers
         # update parameters without bumping them, so a backward pass (after which an optimizer step
         # is to be expected) also marks the packed copies stale.
-        key = tuple((p.data_ptr(), p._version) for _, p in plist) + (str(device),)
+        key = (ptrs, tuple(p._version for _, p in plist), str(device))
         if key == self._packed_key and not self._packed_stale:
             return self._packed
         fc1_ready = self._fc1_fresh and key == self._packed_key and self._fc1_packed is not None
@@ -262,18 +310,8 @@ class ModuleNet(nn.Module):
         pk = {}
         with torch.no_grad():
             f32 = dict(dtype=torch.float32, device=device)
-            # module weights gathered per kind into [V, ...] stacks (one weight group per token)
-            w1 = torch.stack([self._modules[t].conv1.weight for t in self._tokens]).to(**f32).contiguous()
-            w2 = torch.stack([self._modules[t].conv2.weight for t in self._tokens]).to(**f32).contiguous()
-            pk['b_conv1'] = torch.stack([self._modules[t].conv1.bias for t in self._tokens]).to(**f32).contiguous()
-            pk['b_conv2'] = torch.stack([self._modules[t].conv2.bias for t in self._tokens]).to(**f32).contiguous()
-            wp = torch.zeros(nv, c, 2 * c, **f32)
-            bp = torch.zeros(nv, c, **f32)
-            for i, t in enumerate(self._tokens):
-                if self._binary[i]:
-                    wp[i] = self._modules[t].proj.weight.reshape(c, 2 * c)
-                    bp[i] = self._modules[t].proj.bias
-            pk['b_proj'] = bp
+            w1, w2, wp = stk['w1'], stk['w2'], stk['wp']
+            pk['b_conv1'], pk['b_conv2'], pk['b_proj'] = stk['b1'], stk['b2'], stk['bp']
             g33 = c * c * 9
             pk['w_conv1'] = ops.pack_conv_weight(w1, nv, c, c, 9, g33, c * 9, 9)
             pk['w_conv2'] = ops.pack_conv_weight(w2, nv, c, c, 9, g33, c * 9, 9)
@@ -299,7 +337,9 @@ class ModuleNet(nn.Module):
                     if not fc1_ready:
                         ops.fc_weight_to_nhwc(lin.weight.contiguous(), buf, fo, _rup(fo, 128), p_)
                 else:
-                    buf = torch.zeros(_rup(fo, 128), fi, dtype=torch.bfloat16, device=device)
+                    buf = self._packed.get('fc_w', [None] * (li + 1))[li] if self._packed_key is not None else None
+                    if buf is None or buf.device != device or buf.shape != (_rup(fo, 128), fi):
+                        buf = torch.zeros(_rup(fo, 128), fi, dtype=torch.bfloat16, device=device)
                     ops.cast_pad(lin.weight.contiguous(), buf, fo, fi, _rup(fo, 128), fi)
                 fcw.append(buf)
             pk['fc_w'] = fcw
@@ -385,6 +425,15 @@ class ModuleNet(nn.Module):
         ctx.flags = 0 if self.fuse_residual_body else _lib.TREE_UNFUSED
         return ctx
 
+    def _mark(self, name):
+        """With `segment_marks` set to a list, appends (name, timing event on the current stream,
+        host time) at fixed points of a step: where the device and the host spend a step
+        (scripts/step_segments.py)."""
+        if self.segment_marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self.segment_marks.append((name, ev, time.perf_counter()))
+
     def _stem_input(self, x, ws, M, dev):
         """The stem's input as bf16 [rows][196][cin_pad] plus, when the batch is a set of rows of a
         resident table, their int32 row numbers.  Three forms are read in place, without a layout
@@ -455,6 +504,7 @@ class ModuleNet(nn.Module):
             if hp is None or hp.numel() < N * T:
                 hp = ws.bufs['prog_host'] = torch.empty(N * T + N * T // 4, dtype=torch.int64, pin_memory=True)
             hprog = hp[:N * T].view(N, T)
+            self._mark('fwd_begin')
             # the side stream starts behind everything already enqueued here: whatever produced the
             # programs, and the previous call's kernels that still read this set's tile lists
             ready = torch.cuda.Event()
@@ -497,6 +547,7 @@ class ModuleNet(nn.Module):
                                    bias_first=pk['b_conv1'], bias_second=pk['b_conv2'], relu=True,
                                    tiles_offset=16 * M)
 
+            self._mark('scene')
             # programs -> plan -> tile lists on the device
             if arrived is not None:
                 arrived.synchronize()
@@ -529,6 +580,7 @@ class ModuleNet(nn.Module):
                 ws.host_event = torch.cuda.Event()
                 ws.host_event.record(side)
             cur.wait_event(ws.host_event)
+            self._mark('blob')
             self.used_fns = used
             slots = info.slots_total if need_grad else info.slots_fwd
             arena_big = ws.get_capacity('arena', slots * HW * c, torch.bfloat16, dev)
@@ -543,6 +595,7 @@ class ModuleNet(nn.Module):
         if fused:
             tctx.flags |= _lib.TREE_SKIP_LEVEL0
         _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
+        self._mark('tree_fwd')
         # classifier (Module_Model.py:66-93, default: no pooling): conv1x1 + ReLU on the gathered
         # roots, flatten, linear layers
         np128 = _rup(N, 128)
@@ -574,6 +627,7 @@ class ModuleNet(nn.Module):
                 acts.append(a)
                 prev_dim = fo
         st['acts'] = acts
+        self._mark('cls_fwd')
         if need_grad:
             plan.finish()
             total = plan.info.blob_words
@@ -710,7 +764,9 @@ class ModuleNet(nn.Module):
                'gb_conv2': torch.zeros(nv, c, **f32), 'gb_proj': torch.zeros(nv, c, **f32)}
         tctx = self._tree_ctx(st, pk, acc)
         tctx.flags = _lib.TREE_F32
+        self._mark('cls_bwd')
         _lib.check(lib.vqa_tree_backward(plan.handle, C.byref(tctx), ops._stream()))
+        self._mark('tree_bwd')
         gw1 = torch.empty(nv, c, c, 3, 3, **f32)
         gw2 = torch.empty(nv, c, c, 3, 3, **f32)
         gwp = torch.empty(nv, c, 2 * c, 1, 1, **f32)
@@ -789,6 +845,7 @@ class ModuleNet(nn.Module):
         plan, pk, N = st['plan'], st['pk'], st['N']
         dev = dlogits.device
         ws, lib = st['ws'], _lib.load()
+        self._mark('bwd_begin')
         torch.cuda.current_stream(dev).wait_event(st['blob_ready'])     # backward half of the tile lists
         c, p_, cpad, nv = d['c'], d['p'], d['cin_pad'], len(self._tokens)
         np128, np64 = _rup(N, 128), _rup(N, 64)
@@ -859,6 +916,7 @@ class ModuleNet(nn.Module):
                 ops.col_sum(gin, gb, N, fi, fi)
                 grads['classifier.%d.bias' % self._fc_idx[li - 1]] = gb
         dc1 = g   # bf16 [N][196][P], already times (C1 > 0)
+        self._mark('fc_bwd')
 
         # ---- classifier conv1x1: weight/bias gradient, then gradient into the roots' dZ slots
         it_off, it_cnt = plan.section('SAMPLE_ITEMS')
@@ -886,7 +944,9 @@ class ModuleNet(nn.Module):
                'gb_conv2': torch.zeros(nv, c, **f32), 'gb_proj': torch.zeros(nv, c, **f32)}
         tctx = self._tree_ctx(st, pk, acc)
         tctx.wgrad_partial = part.data_ptr()
+        self._mark('cls_bwd')
         _lib.check(lib.vqa_tree_backward(plan.handle, C.byref(tctx), ops._stream()))
+        self._mark('tree_bwd')
         counts = plan.token_counts()
         for i, tok in enumerate(self._tokens):
             if counts[i] == 0:
@@ -924,6 +984,7 @@ class ModuleNet(nn.Module):
                     self.grad_ready_hook(name, gr)
             out.append(gr if p.requires_grad else None)
         torch.cuda.current_stream(dev).wait_event(side_done)
+        self._mark('bwd_end')
         self._packed_stale = True
         if self.backward_done_hook is not None:
             self.backward_done_hook()

@@ -2,7 +2,8 @@
 
 Same update rule, hyper-parameters and skip-if-no-gradient behaviour as the reference's optimizer,
 `torch.optim.Adam(ee.parameters(), lr=..., weight_decay=...)` (`Train_model.py:165-167,315`); state
-entries carry torch's names (`step`, `exp_avg`, `exp_avg_sq`).  All tensors of a step are updated by
+entries carry torch's names (`step`, `exp_avg`, `exp_avg_sq`; the `step` tensors are brought up to date
+when the state is read with state_dict(), between steps the counts are kept as host integers).  All tensors of a step are updated by
 one launch, and when the executor is passed in, the first linear layer's weight (88 % of the
 parameters) is updated by a kernel that also writes the bf16 channels-last copy the executor's GEMM
 reads, so the executor does not re-pack that tensor on its next forward.
@@ -27,18 +28,47 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError('invalid Adam hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._executor = executor
-        self._host = {}          # device -> (pinned byte buffer, device byte buffer, event)
+        self._host = {}          # device -> two [pinned byte buffer, device byte buffer, event, numpy view] + toggle
+        self._recs = {}          # group index -> per-parameter records (see _records)
+        self._chunks_key, self._chunks = None, None
 
     def _tables(self, dev, nbytes):
-        ent = self._host.get(dev)
+        """Two pinned/device buffer pairs per device, used alternately: the host may write the next
+        step's tables while the previous upload is still queued."""
+        ents = self._host.setdefault(dev, [None, None, 0])
+        k = ents[2] = ents[2] ^ 1
+        ent = ents[k]
         if ent is None or ent[0].numel() < nbytes:
             cap = max(2 * nbytes, 1 << 16)
-            ent = [torch.empty(cap, dtype=torch.uint8, pin_memory=True),
-                   torch.empty(cap, dtype=torch.uint8, device=dev), None]
-            self._host[dev] = ent
+            ent = ents[k] = [torch.empty(cap, dtype=torch.uint8, pin_memory=True),
+                             torch.empty(cap, dtype=torch.uint8, device=dev), None, None]
+            ent[3] = ent[0].numpy()
         if ent[2] is not None:
-            ent[2].synchronize()          # the previous step's upload has left the pinned buffer
+            ent[2].synchronize()          # the upload before last has left this pinned buffer
         return ent
+
+    def _records(self, gi, group):
+        """Per parameter of a group: [parameter, state dict or None, numel, step count, m ptr, v ptr].
+        Step counts are kept as Python ints here and written back to the `step` tensors that
+        torch's Adam state carries when the state is read (state_dict)."""
+        recs = self._recs.get(gi)
+        if recs is None or len(recs) != len(group['params']) or any(r[0] is not p for r, p in zip(recs, group['params'])):
+            recs = self._recs[gi] = [[p, None, p.numel(), 0, 0, 0] for p in group['params']]
+        return recs
+
+    def _sync_steps(self):
+        for recs in self._recs.values():
+            for r in recs:
+                if r[1] is not None:
+                    r[1]['step'].fill_(r[3])
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._recs = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -51,64 +81,75 @@ class FusedAdam(torch.optim.Optimizer):
         fc1 = None
         if ex is not None and getattr(ex, 'precision', None) == 'bf16':
             fc1 = ex.classifier[ex._fc_idx[0]].weight
-        for group in self.param_groups:
+        f32 = torch.float32
+        for gi, group in enumerate(self.param_groups):
             lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
-            rows = []
-            for p in group['params']:
+            scale = {}           # step count -> (step_size, 1 / sqrt(bias correction 2))
+            by_dev = {}          # device -> column lists of the tensor table
+            keep = []
+            for idx, r in enumerate(self._records(gi, group)):
+                p = r[0]
                 g = p.grad
                 if g is None:
                     continue          # unused token this step: no update, no step count (as torch)
-                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError('vqa_amd.optim.FusedAdam needs contiguous fp32 parameters on the GPU')
-                if g.is_sparse or g.dtype != torch.float32:
+                if g.dtype != f32 or g.is_sparse:
                     raise RuntimeError('vqa_amd.optim.FusedAdam needs dense fp32 gradients')
                 if not g.is_contiguous():
                     g = g.contiguous()
-                st = self.state[p]
-                if not st:
-                    st['step'] = torch.zeros((), dtype=torch.float32)
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st['step'] += 1
-                t = float(st['step'])
-                step_size = lr / (1.0 - b1 ** t)
-                inv_bc2_sqrt = 1.0 / math.sqrt(1.0 - b2 ** t)
+                st = r[1]
+                if st is None:
+                    if not p.is_cuda or p.dtype != f32 or not p.is_contiguous():
+                        raise RuntimeError('vqa_amd.optim.FusedAdam needs contiguous fp32 parameters on the GPU')
+                    st = self.state[p]
+                    if not st:
+                        st['step'] = torch.zeros((), dtype=f32)
+                        st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    r[1], r[3] = st, int(st['step'])
+                    r[4], r[5] = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+                t = r[3] = r[3] + 1
+                sc = scale.get(t)
+                if sc is None:
+                    sc = scale[t] = (lr / (1.0 - b1 ** t), 1.0 / math.sqrt(1.0 - b2 ** t))
                 if p is fc1:
                     packed = ex._fc1_packed_buffer(p.device)
                     F, P = p.shape[0], ex._dims['p']
-                    _lib.check(lib.vqa_adam_fc1(p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(),
-                                                st['exp_avg_sq'].data_ptr(), packed.data_ptr(), F, P, wd, b1, b2, eps,
-                                                step_size, inv_bc2_sqrt, torch.cuda.current_stream(p.device).cuda_stream))
+                    _lib.check(lib.vqa_adam_fc1(p.data_ptr(), g.data_ptr(), r[4], r[5], packed.data_ptr(), F, P,
+                                                wd, b1, b2, eps, sc[0], sc[1],
+                                                torch.cuda.current_stream(p.device).cuda_stream))
                     ex._fc1_fresh = True
+                    keep.append(g)
                     continue
-                rows.append((p, g, st['exp_avg'], st['exp_avg_sq'], step_size, inv_bc2_sqrt))
-            by_dev = {}
-            for r in rows:
-                by_dev.setdefault(r[0].device, []).append(r)
-            for dev, rs in by_dev.items():
-                tt = np.zeros(len(rs), dtype=_TENSOR)
-                tt['p'] = [r[0].data_ptr() for r in rs]
-                tt['g'] = [r[1].data_ptr() for r in rs]
-                tt['m'] = [r[2].data_ptr() for r in rs]
-                tt['v'] = [r[3].data_ptr() for r in rs]
-                tt['numel'] = [r[0].numel() for r in rs]
-                tt['step_size'] = [r[4] for r in rs]
-                tt['inv_bc2_sqrt'] = [r[5] for r in rs]
-                nch = (tt['numel'] + _CHUNK_ELEMS - 1) // _CHUNK_ELEMS
-                ck = np.zeros(int(nch.sum()), dtype=_CHUNK)
-                ck['tensor'] = np.repeat(np.arange(len(rs), dtype=np.int32), nch)
-                first = np.concatenate([[0], np.cumsum(nch)[:-1]])
-                ck['offset'] = (np.arange(len(ck)) - np.repeat(first, nch)) * _CHUNK_ELEMS
-                tb, cb = tt.tobytes(), ck.tobytes()
-                off = (len(tb) + 255) // 256 * 256
+                cols = by_dev.get(p.device)
+                if cols is None:
+                    cols = by_dev[p.device] = ([], [], [], [], [], [], [], [])
+                cols[0].append(p.data_ptr()); cols[1].append(g.data_ptr()); cols[2].append(r[4]); cols[3].append(r[5])
+                cols[4].append(r[2]); cols[5].append(sc[0]); cols[6].append(sc[1]); cols[7].append(idx)
+                keep.append(g)
+            for dev, cols in by_dev.items():
+                n = len(cols[0])
+                ckey = (gi, dev, tuple(cols[7]))
+                if self._chunks_key != ckey:      # the chunk list depends on which tensors take part only
+                    numel = np.asarray(cols[4], dtype=np.int64)
+                    nch = (numel + _CHUNK_ELEMS - 1) // _CHUNK_ELEMS
+                    ck = np.zeros(int(nch.sum()), dtype=_CHUNK)
+                    ck['tensor'] = np.repeat(np.arange(n, dtype=np.int32), nch)
+                    first = np.concatenate([[0], np.cumsum(nch)[:-1]])
+                    ck['offset'] = (np.arange(len(ck)) - np.repeat(first, nch)) * _CHUNK_ELEMS
+                    self._chunks_key, self._chunks = ckey, ck.view(np.uint8)
+                cb = self._chunks
+                off = (n * _TENSOR.itemsize + 255) // 256 * 256
                 ent = self._tables(dev, off + len(cb))
-                host, devbuf = ent[0], ent[1]
-                host[:len(tb)] = torch.frombuffer(bytearray(tb), dtype=torch.uint8)
-                host[off:off + len(cb)] = torch.frombuffer(bytearray(cb), dtype=torch.uint8)
-                devbuf[:off + len(cb)].copy_(host[:off + len(cb)], non_blocking=True)
+                devbuf, hostnp = ent[1], ent[3]
+                tt = hostnp[:n * _TENSOR.itemsize].view(_TENSOR)
+                tt['p'], tt['g'], tt['m'], tt['v'] = cols[0], cols[1], cols[2], cols[3]
+                tt['numel'], tt['step_size'], tt['inv_bc2_sqrt'] = cols[4], cols[5], cols[6]
+                hostnp[off:off + len(cb)] = cb
+                stream = torch.cuda.current_stream(dev)
+                devbuf[:off + len(cb)].copy_(ent[0][:off + len(cb)], non_blocking=True)
                 ent[2] = torch.cuda.Event()
-                ent[2].record(torch.cuda.current_stream(dev))
-                _lib.check(lib.vqa_adam_tensors(devbuf.data_ptr(), devbuf.data_ptr() + off, len(ck), wd, b1, b2, eps,
-                                                torch.cuda.current_stream(dev).cuda_stream))
-                self._keep = rs          # gradients stay referenced until the next step (kernel still queued)
+                ent[2].record(stream)
+                _lib.check(lib.vqa_adam_tensors(devbuf.data_ptr(), devbuf.data_ptr() + off, len(cb) // _CHUNK.itemsize,
+                                                wd, b1, b2, eps, stream.cuda_stream))
+            self._keep = keep            # gradients stay referenced until the next step (kernels still queued)
         return loss
