@@ -390,3 +390,43 @@ def test_fp32_three_adam_steps_track_the_oracle(vocab):
     with torch.no_grad():
         # the noise-directed moves above feed back into the logits: 7.5e-3 measured
         assert rel(net(x.cuda(), prog.cuda()), ref(x, prog)) <= 2e-2
+
+
+def test_parameter_storage_moves_are_followed(vocab):
+    """On the device the per-token modules' parameters share [V, ...] arrays that the packing kernels
+    read.  Whatever changes a parameter - load_state_dict (in place), an optimizer, .cpu()/.cuda()
+    (new storage), assigning .data - the next forward computes with the current values, and
+    state_dict() returns them under the reference's keys."""
+    from vqa_amd.module_net import ModuleNet
+    dims = small_dims(128)
+    sd_a = synth.synth_state_dict(31, vocab, **dims)
+    sd_b = synth.synth_state_dict(32, vocab, **dims)
+    prog = torch.from_numpy(synth.synth_programs(33, 24, vocab, max_len=14, max_nodes=12)).cuda()
+    x = torch.from_numpy(synth.synth_features(33, 24, dims['feature_dim'])).cuda()
+    out = {}
+    for name, sd in (('a', sd_a), ('b', sd_b)):
+        net = ModuleNet(False, vocab, **dims)
+        net.load_state_dict(sd)
+        net.cuda().eval()
+        with torch.no_grad():
+            out[name] = net(x, prog).clone()
+    assert not torch.equal(out['a'], out['b'])
+    tok = 'filter_color[red]'
+    with torch.no_grad():
+        w = net._modules[tok].conv1.weight
+        assert w.data_ptr() == net._stacks['w1'][net._tokens.index(tok)].data_ptr()      # a row of the shared array
+        net.load_state_dict(sd_a)                                   # in place: written through
+        assert torch.equal(net(x, prog), out['a'])
+        for k, v in net.state_dict().items():
+            assert torch.equal(v.cpu(), torch.as_tensor(sd_a[k])), k
+        net.cpu()
+        net.load_state_dict(sd_b)
+        net.cuda()                                                  # new storage: re-stacked
+        assert torch.equal(net(x, prog), out['b'])
+        used = [t for t, c in zip(net._tokens, net.last_token_counts) if c > 0 and t != 'scene'][0]
+        p = net._modules[used].conv2.weight
+        p.data = torch.zeros_like(p.data)                           # storage replaced behind the module's back
+        changed = net(x, prog).clone()
+        assert not torch.equal(changed, out['b'])
+        p.copy_(torch.as_tensor(sd_b[used + '.conv2.weight']))       # in place (version counter moves)
+        assert torch.equal(net(x, prog), out['b'])
