@@ -15,7 +15,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
   tag=$(echo $set | cut -d' ' -f1)
   VQA_BENCH_NO_KERNEL_TIMING=1 timeout -s KILL 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/prof_pmc_$tag -- \
       python bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $O/prof_pmc_$tag.err || exit 1
-  for k in resblock_tiles "wgrad_tiles_kernel<9>" "gemm_kernel" adam_fc1; do
+  for k in resblock_tiles "wgrad_tiles_kernel<9>" "gemm256_kernel" adam_fc1; do
     echo "== $k" >> $O/prof_pmc_summary.txt
     python scripts/pmc_dispatch.py $O/prof_pmc_$tag "$k" 2 >> $O/prof_pmc_summary.txt
   done
