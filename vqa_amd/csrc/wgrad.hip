@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
     choff += khalf * 64;
     const int32_t* sslots = which ? p.src1_slots : p.src_slots;
 
-    // Prefetch registers are named scalars (not arrays): loop-carried arrays end up in scratch.
-    uint4 x0, x1, x2, x3, x4, x5, x6, d0, d1, d2, d3, d4, d5, d6;
+    // Staging registers are named scalars (not arrays): loop-carried arrays end up in scratch.  Two
+    // sets (a, b); the second one is used by the single-tap kernel only.
+    uint4 x0a, x1a, x2a, x3a, x4a, x5a, x6a, d0a, d1a, d2a, d3a, d4a, d5a, d6a;
+    uint4 x0b, x1b, x2b, x3b, x4b, x5b, x6b, d0b, d1b, d2b, d3b, d4b, d5b, d6b;
 #define XLOAD(i, var)                                                                          \
     {                                                                                          \
         const int e = tid + 256 * i, pix = min(e >> 3, VQA_HW - 1), pc = e & 7;                \
@@ -60,13 +62,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
         const int e = tid + 256 * i, pix = min(e >> 3, VQA_HW - 1), pc = e & 7;                \
         var = *(const uint4*)(dp + (int64_t)pix * p.dy_pix_stride * 2 + pc * 16);              \
     }
-#define LOAD_NODE(n)                                                                           \
+#define LOAD_NODE(n, S)                                                                        \
     {                                                                                          \
         const int ss = sslots[it.first + (n)], ds = p.dy_slots[it.first + (n)];                \
         const char* sp = (const char*)p.src + ((int64_t)ss * p.src_slot_stride + choff) * 2;   \
         const char* dp = (const char*)p.dy + ((int64_t)ds * p.dy_slot_stride + oslice * 64) * 2; \
-        XLOAD(0, x0) XLOAD(1, x1) XLOAD(2, x2) XLOAD(3, x3) XLOAD(4, x4) XLOAD(5, x5) XLOAD(6, x6) \
-        DLOAD(0, d0) DLOAD(1, d1) DLOAD(2, d2) DLOAD(3, d3) DLOAD(4, d4) DLOAD(5, d5) DLOAD(6, d6) \
+        XLOAD(0, x0##S) XLOAD(1, x1##S) XLOAD(2, x2##S) XLOAD(3, x3##S) XLOAD(4, x4##S) XLOAD(5, x5##S) XLOAD(6, x6##S) \
+        DLOAD(0, d0##S) DLOAD(1, d1##S) DLOAD(2, d2##S) DLOAD(3, d3##S) DLOAD(4, d4##S) DLOAD(5, d5##S) DLOAD(6, d6##S) \
     }
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define XSTORE(i, var)                                                                         \
@@ -89,10 +91,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
             bsum[6] += __uint_as_float(var.w << 16); bsum[7] += __uint_as_float(var.w & 0xFFFF0000u); \
         }                                                                                      \
     }
-#define STORE_NODE()                                                                           \
+#define STORE_NODE(S)                                                                          \
     {                                                                                          \
-        XSTORE(0, x0) XSTORE(1, x1) XSTORE(2, x2) XSTORE(3, x3) XSTORE(4, x4) XSTORE(5, x5) XSTORE(6, x6) \
-        DSTORE(0, d0) DSTORE(1, d1) DSTORE(2, d2) DSTORE(3, d3) DSTORE(4, d4) DSTORE(5, d5) DSTORE(6, d6) \
+        XSTORE(0, x0##S) XSTORE(1, x1##S) XSTORE(2, x2##S) XSTORE(3, x3##S) XSTORE(4, x4##S) XSTORE(5, x5##S) XSTORE(6, x6##S) \
+        DSTORE(0, d0##S) DSTORE(1, d1##S) DSTORE(2, d2##S) DSTORE(3, d3##S) DSTORE(4, d4##S) DSTORE(5, d5##S) DSTORE(6, d6##S) \
     }
 
     f32x4 acc[TAPS][4];
@@ -106,13 +108,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
     const int xoff = (prow * 16 + pcol) * XH_STRIDE + (wave * 16 + 4 * pp) * 2;   // + tap, + kk, + r
     const int doff = (prow * 16 + pcol) * DY_STRIDE + (4 * pp) * 2;               // + 32*ot, + kk, + r
 
-    for (int n = 0; n < it.count; n++) {
-        // no register prefetch across the MFMA phase: the partner workgroup on this CU covers the
-        // round trip, and 14 more live registers would spill
-        LOAD_NODE(n)
-        __syncthreads();          // zero fill done / previous node's reads done
-        STORE_NODE()
-        __syncthreads();
+    // the MFMA phase over the staged node: 7 k-steps of two image rows
+    auto mfma_phase = [&]() {
 #pragma unroll 1
         for (int kk = 0; kk < 7; kk++) {
             const char* xb = xh + xoff + kk * 32 * XH_STRIDE;
@@ -142,6 +139,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
                 if (t + 2 < TAPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
+        }
+    };
+
+    if constexpr (TAPS == 1) {
+        // One tap: a node is 28 MFMAs per wave against ~75 KB of staging, so the loop is all load
+        // latency; with only 16 accumulator registers there is room to keep the next TWO nodes'
+        // loads in flight while one is staged and multiplied.
+        LOAD_NODE(0, a)
+        if (it.count > 1) LOAD_NODE(1, b)
+        for (int n = 0; n < it.count; n += 2) {
+            __syncthreads();
+            STORE_NODE(a)
+            if (n + 2 < it.count) LOAD_NODE(n + 2, a)
+            __syncthreads();
+            mfma_phase();
+            if (n + 1 < it.count) {
+                __syncthreads();
+                STORE_NODE(b)
+                if (n + 3 < it.count) LOAD_NODE(n + 3, b)
+                __syncthreads();
+                mfma_phase();
+            }
+        }
+    } else {
+        for (int n = 0; n < it.count; n++) {
+            // no register prefetch across the MFMA phase: the partner workgroup on this CU covers the
+            // round trip, and 14 more live registers would spill
+            LOAD_NODE(n, a)
+            __syncthreads();          // zero fill done / previous node's reads done
+            STORE_NODE(a)
+            __syncthreads();
+            mfma_phase();
         }
     }
 
