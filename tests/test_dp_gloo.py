@@ -85,3 +85,67 @@ def test_shard_rows_matches_dataparallel_scatter():
         got = [shard_rows(n, r, w) for r in range(w)]
         assert [b - a for a, b in got if b > a] == chunks
         assert got[0][0] == 0 and max(b for _, b in got) == n
+
+
+class _FakeGroupedNet(nn.Module):
+    """Per-token gradients handed over as rows of [V, ...] arrays (grad_group_hook), as ModuleNet does."""
+
+    def __init__(self):
+        super().__init__()
+        self._tokens = ['<NULL>', 'scene', 'count']
+        self.stem = nn.Parameter(torch.zeros(5, 5))
+        self.w = nn.ParameterList([nn.Parameter(torch.zeros(600, 600)) for _ in self._tokens])
+        self.b = nn.ParameterList([nn.Parameter(torch.zeros(4)) for _ in self._tokens])
+        self.grad_ready_hook = self.grad_group_hook = self.backward_done_hook = None
+        self.last_token_counts = None
+
+    def _param_groups(self):
+        out = [('stem.0.weight', self.stem)]
+        for i, t in enumerate(self._tokens):
+            out += [(t + '.conv1.weight', self.w[i]), (t + '.conv1.bias', self.b[i])]
+        return out
+
+    def forward(self, x, program):
+        return x.sum() * 0
+
+    def fake_backward(self, stem, gw, gb):
+        self.grad_ready_hook('stem.0.weight', stem)
+        self.grad_group_hook(gw, {t + '.conv1.weight': i for i, t in enumerate(self._tokens)})
+        self.grad_group_hook(gb, {t + '.conv1.bias': i for i, t in enumerate(self._tokens)})
+        # autograd would install views of the arrays for the tokens this rank used
+        for i, c in enumerate(self.last_token_counts):
+            self.w[i].grad = gw[i] if c else None
+            self.b[i].grad = gb[i] if c else None
+        self.backward_done_hook()
+
+
+def _worker_grouped(rank, world, port):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        net = _FakeGroupedNet()
+        dp = DataParallelExecutor(net)
+        for step in range(2):
+            # rank 0 uses <NULL> and scene, rank 1 scene only, nobody count; the arrays hold zeros for unused tokens
+            net.last_token_counts = [2, 1, 0] if rank == 0 else [0, 3, 0]
+            dp(torch.zeros(1), None)
+            gw = torch.zeros(3, 600, 600)
+            gb = torch.zeros(3, 4)
+            gw[1], gb[1] = 10.0 * (rank + 1) + step, rank + 1.0
+            if rank == 0:
+                gw[0], gb[0] = 7.0, 3.0
+            net.fake_backward(torch.full((5, 5), float(rank)), gw, gb)
+            dp.finish_grad_sync()
+            assert torch.allclose(net.stem.grad, torch.full((5, 5), 0.5))
+            assert torch.allclose(net.w[1].grad, torch.full((600, 600), 15.0 + step))
+            assert torch.allclose(net.b[1].grad, torch.full((4,), 1.5))
+            assert torch.allclose(net.w[0].grad, torch.full((600, 600), 3.5))       # rank 1 contributed zeros
+            assert torch.allclose(net.b[0].grad, torch.full((4,), 1.5))
+            assert net.w[2].grad is None and net.b[2].grad is None                  # unused everywhere
+            assert net.w[1].grad.data_ptr() == gw[1].data_ptr()                     # reduced in place
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grouped_gradients_two_ranks_gloo():
+    mp.spawn(_worker_grouped, args=(2, _free_port()), nprocs=2, join=True)

@@ -9,9 +9,12 @@ all-reduce:
   * the first linear layer's gradient (411 MB of the 470 MB) is produced first in backward; its
     all-reduce is launched the moment its kernel is enqueued and runs on RCCL's stream under the
     whole module-tree backward
-  * every other gradient goes into one flat fp32 bucket with a fixed layout, reduced when backward
-    ends; a token that no program of this rank used contributes zeros, so every rank issues
+  * the per-token modules' gradients leave the executor as rows of a few [V, ...] arrays (one per
+    parameter kind): the large ones are reduced in place, array by array, as soon as they are
+    complete; a token that no program of this rank used has a row of zeros, so every rank issues
     identical collectives whatever its programs were
+  * what is left (stem, classifier conv, biases: a dozen tensors) goes into one flat fp32 bucket
+    with a fixed layout, reduced when backward ends
   * a parameter keeps `grad is None` only if NO rank used its token, which is what the
     reference's reduce-add over replicas gives (Adam then skips it, weight decay included)
 
@@ -47,14 +50,19 @@ class DataParallelExecutor:
             for n in self._names:
                 if n.startswith(tok + '.'):
                     self._token_of[n] = ti
+        self._by_name = dict(self._params)
         self._flat = None
         self._layout = None
+        self._groups = []            # (array, {name: row}) handed over by the executor this step
+        self._grouped_names = set()  # names that arrive as rows of such arrays (fixed after the first step)
+        self._small_groups = []
         self._works = []
         self._direct = {}
         self._small = {}
         self._presence = None
         self._pending = False
         net.grad_ready_hook = self._on_grad
+        net.grad_group_hook = self._on_group
         net.backward_done_hook = self._on_backward_done
         self._avg = dist.get_backend(process_group) == 'nccl'
 
@@ -83,15 +91,31 @@ class DataParallelExecutor:
         else:
             self._small[name] = grad
 
+    def _on_group(self, array, rows):
+        """`array` [V, ...] holds the gradients of one parameter kind of every token (zeros where a
+        token was not used); rows maps parameter name -> row."""
+        self._pending = True
+        if self._flat is not None and not self._grouped_names.issuperset(rows):
+            self._flat = None                # first sight of these names after the bucket was laid out
+        self._grouped_names.update(rows)
+        if array.numel() * array.element_size() >= (1 << 20) and array.is_contiguous():
+            self._groups.append((array, rows))
+            self._reduce(array)              # in place; the parameters' .grad are views of it
+        else:
+            self._small_groups.append((array, rows))
+
     def _ensure_flat(self, device):
         if self._flat is not None and self._flat.device == device:
             return
         layout, off = {}, 0
         for n, p in self._params:
-            if p.numel() * 4 >= self.direct_bytes:
+            if p.numel() * 4 >= self.direct_bytes or n in self._grouped_names:
                 continue
             layout[n] = (off, p.numel())
             off += p.numel()
+        for k, (array, _) in enumerate(self._small_groups):
+            layout[('group', k)] = (off, array.numel())
+            off += array.numel()
         self._layout = layout
         self._flat = torch.zeros(off, dtype=torch.float32, device=device)
 
@@ -102,6 +126,9 @@ class DataParallelExecutor:
         for n, g in self._small.items():
             off, cnt = self._layout[n]
             self._flat[off:off + cnt].copy_(g.reshape(-1))
+        for k, (array, _) in enumerate(self._small_groups):
+            off, cnt = self._layout[('group', k)]
+            self._flat[off:off + cnt].copy_(array.reshape(-1))
         self._reduce(self._flat)
 
     # ---------------------------------------------------------------- after loss.backward()
@@ -118,7 +145,24 @@ class DataParallelExecutor:
         scale = 1.0 if self._avg else 1.0 / self.world
         if not self._avg:
             self._flat.mul_(scale)
+        groups = list(self._groups)
+        if not self._avg:
+            for array, _ in groups:
+                array.mul_(scale)            # reduced in place as sums
+        for k, (array, rows) in enumerate(self._small_groups):     # these travelled in the flat bucket
+            off, cnt = self._layout[('group', k)]
+            groups.append((self._flat[off:off + cnt].view(array.shape), rows))
+        for array, rows in groups:
+            for n, row in rows.items():
+                ti = self._token_of.get(n)
+                p = self._by_name[n]
+                if ti is not None and present is not None and not present[ti]:
+                    p.grad = None             # unused on every rank
+                else:
+                    p.grad = array[row].view(p.shape)
         for n, p in self._params:
+            if n in self._grouped_names:
+                continue
             if n in self._direct:
                 g = self._direct[n]
                 if not self._avg:
@@ -134,6 +178,7 @@ class DataParallelExecutor:
             off, cnt = self._layout[n]
             p.grad = self._flat[off:off + cnt].view(p.shape)
         self._direct, self._small, self._presence, self._pending = {}, {}, None, False
+        self._groups, self._small_groups = [], []
 
     # convenience passthroughs
     def parameters(self):

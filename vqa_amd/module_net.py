@@ -227,6 +227,7 @@ class ModuleNet(nn.Module):
         # (the tolerance configuration: results within 1e-3 of the reference's fp32 arithmetic)
         self.precision = 'bf16'
         self.grad_ready_hook = None   # set by the data-parallel wrapper: called as (name, grad tensor)
+        self.grad_group_hook = None   # likewise: (array [V, ...], {parameter name: row}) per kind of per-token parameter
         self.backward_done_hook = None
         self.last_token_counts = None
         self.keep_state = False       # tests: keep the last call's buffers in self.last_state
@@ -947,6 +948,14 @@ class ModuleNet(nn.Module):
         self._mark('cls_bwd')
         _lib.check(lib.vqa_tree_backward(plan.handle, C.byref(tctx), ops._stream()))
         self._mark('tree_bwd')
+        if self.grad_group_hook is not None:
+            # the per-token gradients are rows of these arrays (zeros for tokens this batch did not use)
+            for arr, key, binary_only in ((gw1, '.conv1.weight', False), (gw2, '.conv2.weight', False),
+                                          (gwp, '.proj.weight', True), (acc['gb_conv1'], '.conv1.bias', False),
+                                          (acc['gb_conv2'], '.conv2.bias', False), (acc['gb_proj'], '.proj.bias', True)):
+                rows = {tok + key: i for i, tok in enumerate(self._tokens) if self._binary[i] or not binary_only}
+                self.grad_group_hook(arr, rows)
+                emitted.update(rows)
         counts = plan.token_counts()
         for i, tok in enumerate(self._tokens):
             if counts[i] == 0:
