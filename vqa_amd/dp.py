@@ -63,6 +63,8 @@ class DataParallelExecutor:
         self._pending = False
         net.grad_ready_hook = self._on_grad
         net.grad_group_hook = self._on_group
+        net.plan_ready_hook = self._on_plan
+        self._aux, self._presence_host, self._presence_event, self._presence_launched = None, None, None, False
         net.backward_done_hook = self._on_backward_done
         self._avg = dist.get_backend(process_group) == 'nccl'
 
@@ -71,12 +73,37 @@ class DataParallelExecutor:
         return self.forward(x, program)
 
     def forward(self, x, program):
+        self._presence_launched = False
         out = self.net(x, program)
         counts = getattr(self.net, 'last_token_counts', None)
-        if counts is not None and torch.is_grad_enabled():
+        if counts is not None and torch.is_grad_enabled() and not self._presence_launched:
             self._presence = torch.as_tensor(counts, dtype=torch.int32).clamp(max=1).to(out.device)
             self._works.append(dist.all_reduce(self._presence, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
         return out
+
+    def _on_plan(self, counts, device):
+        """Called by the executor as soon as the batch's programs are parsed (before its forward
+        launches): which tokens any rank uses is agreed on here, on a stream of its own, and is in
+        host memory long before finish_grad_sync() asks for it - the host never waits for the
+        device's backward pass to learn it."""
+        if not torch.is_grad_enabled():
+            return
+        if device.type != 'cuda':
+            return
+        if self._aux is None:
+            self._aux = torch.cuda.Stream(device)
+            self._presence_host = torch.zeros(len(counts), dtype=torch.int32).pin_memory()
+        if self._presence_event is not None:
+            self._presence_event.synchronize()       # the pinned buffer's previous use
+        with torch.cuda.stream(self._aux):
+            self._presence_host.copy_(torch.as_tensor(counts, dtype=torch.int32).clamp(max=1))
+            self._presence = self._presence_host.to(device, non_blocking=True)
+            work = dist.all_reduce(self._presence, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
+            work.wait()                              # the aux stream waits, not the host
+            self._presence_host.copy_(self._presence, non_blocking=True)
+            self._presence_event = torch.cuda.Event()
+            self._presence_event.record(self._aux)
+        self._presence_launched = True
 
     # ---------------------------------------------------------------- backward hooks
     def _reduce(self, t):
@@ -140,7 +167,10 @@ class DataParallelExecutor:
             w.wait()
         self._works = []
         present = None
-        if self._presence is not None:
+        if self._presence_launched:
+            self._presence_event.synchronize()
+            present = self._presence_host.tolist()
+        elif self._presence is not None:
             present = self._presence.cpu().tolist()
         scale = 1.0 if self._avg else 1.0 / self.world
         if not self._avg:
