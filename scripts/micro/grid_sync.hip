@@ -1,3 +1,4 @@
+// build: hipcc -O3 --offload-arch=gfx950 grid_sync.hip -o grid_sync
 // Cost of a grid-wide barrier on MI355X: 512 workgroups x 256 threads (2 per CU, the residency of the
 // fused node kernel: 74 KB of LDS each), cooperative launch, cooperative_groups grid sync.
 // Between barriers each workgroup writes a line another workgroup (on another XCD) reads afterwards,

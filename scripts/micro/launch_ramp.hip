@@ -1,3 +1,4 @@
+// build: hipcc -O3 --offload-arch=gfx950 launch_ramp.hip -o launch_ramp
 // How long does the device take to get N workgroups of the fused node kernel's shape going?
 // Kernels that do nothing but touch LDS once, with 256 threads, varying LDS size and register count.
 #include <hip/hip_runtime.h>
