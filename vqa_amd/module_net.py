@@ -614,8 +614,13 @@ class ModuleNet(nn.Module):
         for li, fo in enumerate(fcs):
             lin = self.classifier[self._fc_idx[li]]
             last = li == len(fcs) - 1
-            tiles = (np128 // 128) * (_rup(fo, 128) // 128)
-            split = max(1, min(prev_dim // 64, 16, -(-512 // tiles)))
+            # split-k so that the launch fills the device: 512 workgroups of the 128 x 128-tile kernel
+            # (two per CU), or 256 of the 256 x 256-tile kernel that large aligned problems take
+            if N % 256 == 0 and fo % 256 == 0 and (N // 256) * (fo // 256) * 8 >= 128:
+                split = max(1, min(prev_dim // 64, 256 // ((N // 256) * (fo // 256))))
+            else:
+                tiles = (np128 // 128) * (_rup(fo, 128) // 128)
+                split = max(1, min(prev_dim // 64, 16, -(-512 // tiles)))
             acc = ws.get('fc_acc%d' % li, split * N * fo, torch.float32, dev)
             ops.gemm(acts[-1], pk['fc_w'][li], acc, N, fo, prev_dim, lda=prev_dim, ldb=prev_dim, ldc=fo,
                      split_k=split)
