@@ -210,6 +210,18 @@ def main():
                  'forward and input-gradient launches)' if dominant == 'resblock' else
                  'conv_tiles_kernel<9> (grouped 3x3 implicit-GEMM conv: forward and input-gradient launches)')
         ach = k['flops'] / (k['ms'] * 1e-3) / 1e12 if k['ms'] > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel cannot be counted from inside this process: they
+        # come from the committed rocprofv3 --pmc passes over this same default workload
+        # (scripts/refresh_profiles.sh, scripts/pmc_traffic.py), and only for that workload
+        traffic, traffic_note = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc_resblock_traffic.json')
+        if (dominant == 'resblock' and a.batch == 1024 and a.max_nodes == 27 and a.max_len == 30 and
+                a.features == 'fp32' and os.path.exists(tpath)):
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj['hbm_bytes_per_launch']
+            traffic_note = ('bytes per launch, mean over %d launches; %s; algorithmic: 2-3 maps of 50 176 B read and 2 written '
+                            'per tile plus 0.59 MB of weights per token and launch' % (tj['launches'], tj['method']))
         out = {
             'metric': 'programs/sec (module-net fwd+bwd, whole node)',
             'value': a.batch * world * a.steps / dt,
@@ -234,7 +246,7 @@ def main():
             'mfma_peak_frac': flops * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
+                         'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
                          'launches': k['launches'], 'avg_launch_ms': k['ms'] / max(k['launches'], 1),
                          'sampled_steps': sampled_steps},
             'kernels': {n: {'launches': v['launches'],

@@ -19,6 +19,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
     echo "== $k" >> $O/prof_pmc_summary.txt
     python scripts/pmc_dispatch.py $O/prof_pmc_$tag "$k" 2 >> $O/prof_pmc_summary.txt
   done
-  rm -rf $O/prof_pmc_$tag
+  if [ "$tag" = "SQ_VALU_MFMA_BUSY_CYCLES" ]; then rm -rf $O/prof_pmc_$tag; fi
 done
+python scripts/pmc_traffic.py $O/prof_pmc_FETCH_SIZE $O/prof_pmc_WRITE_SIZE resblock_tiles $O/prof_pmc_resblock_traffic.json || exit 1
+rm -rf $O/prof_pmc_FETCH_SIZE $O/prof_pmc_WRITE_SIZE
 echo done
