@@ -23,6 +23,17 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
     p -= step_size * m / (sqrtf(v) * inv_bc2_sqrt + eps);
 }
 
+// streaming accesses: every element is touched once per step, so it should not displace the weights
+// and tile lists the next kernels find in L2
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ntload4(const float* a) {
+    const f32x4n v = __builtin_nontemporal_load((const f32x4n*)a);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void ntstore4(float* a, float4 x) {
+    __builtin_nontemporal_store((f32x4n){x.x, x.y, x.z, x.w}, (f32x4n*)a);
+}
+
 // chunk c: elements [offset, offset + 4096) of tensor chunks[c].tensor
 __global__ __launch_bounds__(256) void adam_tensors_kernel(const vqa_adam_tensor* __restrict__ tensors,
                                                            const vqa_adam_chunk* __restrict__ chunks, float wd,
@@ -33,13 +44,13 @@ __global__ __launch_bounds__(256) void adam_tensors_kernel(const vqa_adam_tensor
     const int64_t end = min(ck.offset + (int64_t)4096, t.numel);
     if ((t.numel & 3) == 0) {       // 16-byte accesses
         for (int64_t e = ck.offset + threadIdx.x * 4; e < end; e += 1024) {
-            float4 p = *(float4*)(t.p + e), m = *(float4*)(t.m + e), v = *(float4*)(t.v + e);
-            const float4 g = *(const float4*)(t.g + e);
+            float4 p = ntload4(t.p + e), m = ntload4(t.m + e), v = ntload4(t.v + e);
+            const float4 g = ntload4(t.g + e);
             adam1(p.x, g.x, m.x, v.x, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
             adam1(p.y, g.y, m.y, v.y, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
             adam1(p.z, g.z, m.z, v.z, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
             adam1(p.w, g.w, m.w, v.w, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
-            *(float4*)(t.p + e) = p; *(float4*)(t.m + e) = m; *(float4*)(t.v + e) = v;
+            ntstore4(t.p + e, p); ntstore4(t.m + e, m); ntstore4(t.v + e, v);
         }
     } else {
         for (int64_t e = ck.offset + threadIdx.x; e < end; e += 256) {
@@ -79,8 +90,8 @@ __global__ __launch_bounds__(256) void adam_fc1_kernel(float* __restrict__ p, co
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int q = min(tid + 256 * (i0 + i), 64 * 49 - 1);       // float4 index in the tile
-            pv[i] = *(const float4*)(p + base + q * 4); gv[i] = *(const float4*)(g + base + q * 4);
-            mv[i] = *(const float4*)(m + base + q * 4); vv[i] = *(const float4*)(v + base + q * 4);
+            pv[i] = ntload4(p + base + q * 4); gv[i] = ntload4(g + base + q * 4);
+            mv[i] = ntload4(m + base + q * 4); vv[i] = ntload4(v + base + q * 4);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -90,8 +101,8 @@ __global__ __launch_bounds__(256) void adam_fc1_kernel(float* __restrict__ p, co
                 adam1(pv[i].y, gv[i].y, mv[i].y, vv[i].y, wd, b1c, beta2, b2c, step_size, inv_bc2_sqrt, eps);
                 adam1(pv[i].z, gv[i].z, mv[i].z, vv[i].z, wd, b1c, beta2, b2c, step_size, inv_bc2_sqrt, eps);
                 adam1(pv[i].w, gv[i].w, mv[i].w, vv[i].w, wd, b1c, beta2, b2c, step_size, inv_bc2_sqrt, eps);
-                *(float4*)(p + base + q * 4) = pv[i]; *(float4*)(m + base + q * 4) = mv[i];
-                *(float4*)(v + base + q * 4) = vv[i];
+                ntstore4(p + base + q * 4, pv[i]); ntstore4(m + base + q * 4, mv[i]);
+                ntstore4(v + base + q * 4, vv[i]);
                 const int c = q / 49, pix = (q - c * 49) * 4;
                 uint32_t* t = (uint32_t*)(tile + c * 198 + pix);
                 t[0] = cvt_pk_bf16((f32x2){pv[i].x, pv[i].y});

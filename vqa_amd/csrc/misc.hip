@@ -3,6 +3,8 @@
 #include "vqa_dev.h"
 #include "plan.h"
 
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+
 #define CHECK_LAUNCH(name)                                                                    \
     do {                                                                                      \
         hipError_t e_ = hipGetLastError();                                                    \
@@ -28,7 +30,11 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     for (int i = 0; i < 13; i++) {
         const int f = tid + 256 * i;            // float4 index: channel f / 49, pixels 4 * (f % 49)..+3
         const int c = f / 49;
-        v[i] = (f < 64 * 49 && c < cvalid) ? xs[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // streaming read: the fp32 input is touched once
+        if (f < 64 * 49 && c < cvalid) {
+            const f32x4n t = __builtin_nontemporal_load((const f32x4n*)(xs + f));
+            v[i] = make_float4(t[0], t[1], t[2], t[3]);
+        } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 13; i++) {
