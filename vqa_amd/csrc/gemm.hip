@@ -293,7 +293,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(vqa_gemm_params p) {
             for (int it = 0; it < 16; it++) {
                 const int r = it * 8 + wave;
                 const f32x4 v = *(const f32x4*)(stage + r * GB_STAGE_LD + cg);
-                *(float4*)(cbase + (int64_t)(mbase + r) * p.ldc + n0 + cg) = make_float4(v[0], v[1], v[2], v[3]);
+                float* cp = cbase + (int64_t)(mbase + r) * p.ldc + n0 + cg;
+                // a result that is not split over k is final and far larger than the caches (the first
+                // linear layer's 411 MB weight gradient): stream it, whole 1 KiB rows per instruction
+                if (p.split_k == 1) __builtin_nontemporal_store(v, (f32x4*)cp);
+                else *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     }
