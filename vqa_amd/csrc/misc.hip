@@ -4,6 +4,7 @@
 #include "plan.h"
 
 typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2n __attribute__((ext_vector_type(2)));
 
 #define CHECK_LAUNCH(name)                                                                    \
     do {                                                                                      \
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void transpose_hw_c_kernel(const bf16_t* __res
     const uint32_t* tw = (const uint32_t*)tile;
     for (int q = tid; q < 64 * 49; q += 256) {
         const int c = q / 49, k = q - c * 49;
-        os[q] = make_uint2(tw[c * 99 + 2 * k], tw[c * 99 + 2 * k + 1]);
+        __builtin_nontemporal_store((u32x2n){tw[c * 99 + 2 * k], tw[c * 99 + 2 * k + 1]}, (u32x2n*)(os + q));   // read once, much later
     }
 }
 

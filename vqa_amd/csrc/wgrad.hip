@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (items[j].group != grp) continue;
         const float* part = partial + ((int64_t)(j * oslices + oslice) * k_chunks + kchunk) * (TAPS * 8192) + ocl * 128 + il;
 #pragma unroll
-        for (int t = 0; t < TAPS; t++) acc[t] += part[t * 8192];
+        for (int t = 0; t < TAPS; t++) acc[t] += __builtin_nontemporal_load(part + t * 8192);   // each partial is read once
     }
     float* o = out + (int64_t)grp * out_g_stride + (int64_t)idx * TAPS;
 #pragma unroll
