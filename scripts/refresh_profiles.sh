@@ -22,5 +22,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
   if [ "$tag" = "SQ_VALU_MFMA_BUSY_CYCLES" ]; then rm -rf $O/prof_pmc_$tag; fi
 done
 python scripts/pmc_traffic.py $O/prof_pmc_FETCH_SIZE $O/prof_pmc_WRITE_SIZE resblock_tiles $O/prof_pmc_resblock_traffic.json || exit 1
+python scripts/pmc_step_traffic.py $O/prof_pmc_FETCH_SIZE $O/prof_pmc_WRITE_SIZE $O/prof_pmc_step_traffic.json || exit 1
 rm -rf $O/prof_pmc_FETCH_SIZE $O/prof_pmc_WRITE_SIZE
 echo done

@@ -38,8 +38,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
     char* dyt = smem + XH_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4, q = l15 >> 2, pp = lane & 3;
-    const vqa_wgrad_item it = p.items[blockIdx.x];
-    const int oslice = blockIdx.y, kchunk = blockIdx.z >> 1, khalf = blockIdx.z & 1;
+    // Workgroup -> (item, output slice, source half).  The workgroups of one item read the same maps
+    // (every source half once per output slice and the other way round): dispatched far apart they
+    // each fetched them from HBM (measured: 4.6 GB per step against 2.2 GB algorithmic).  Consecutive
+    // workgroup ids go round-robin over the 8 XCDs, so XCD x takes items x, x + 8, ... and runs the
+    // siblings of an item back to back: the second to last reader of a map finds it in that XCD's L2.
+    const int oslices = p.n_out >> 6, zs = p.k_chunks * 2, sibs = oslices * zs;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int item = (j / sibs) * 8 + xcd, sib = j % sibs;
+    if (item >= p.num_items) return;             // grid is padded to whole groups of 8 items
+    const vqa_wgrad_item it = p.items[item];
+    const int oslice = sib % oslices, kchunk = (sib / oslices) >> 1, khalf = (sib / oslices) & 1;
 
     for (int i = tid; i < WGRAD_LDS / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
 
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
     // accumulators out: row = source channel, col = output channel
     if (p.partial) {
         // block of this workgroup: [tap][64 output channels][128 source channels] fp32
-        float* part = p.partial + ((int64_t)(blockIdx.x * gridDim.y + oslice) * (gridDim.z >> 1) + kchunk) * (TAPS * 8192) + khalf * 64;
+        float* part = p.partial + ((int64_t)(item * oslices + oslice) * p.k_chunks + kchunk) * (TAPS * 8192) + khalf * 64;
 #pragma unroll
         for (int t = 0; t < TAPS; t++)
 #pragma unroll
@@ -228,7 +237,9 @@ extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* st
         (void)hipFuncSetAttribute((const void*)wgrad_tiles_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS);
         attr_set = true;
     }
-    dim3 grid(p->num_items, p->n_out / 64, p->k_chunks * 2), block(256);
+    const int64_t blocks = (int64_t)((p->num_items + 7) / 8) * 8 * (p->n_out / 64) * (p->k_chunks * 2);
+    if (blocks > 0x7fffffff) { vqa_set_error("vqa_wgrad_tiles: too many work items"); return VQA_EINVAL; }
+    dim3 grid((unsigned)blocks), block(256);
     VqaProfScope prof(taps == 9 ? VQA_K_WGRAD9 : VQA_K_WGRAD1,
                       2.0 * VQA_HW * taps * p->k_chunks * 128.0 * p->n_out * p->total_nodes,
                       (double)p->total_nodes * VQA_HW * 2.0 * (p->k_chunks * 128 + p->n_out), (hipStream_t)stream);
