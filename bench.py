@@ -222,6 +222,15 @@ def main():
             traffic = tj['hbm_bytes_per_launch']
             traffic_note = ('bytes per launch, mean over %d launches; %s; algorithmic: 2-3 maps of 50 176 B read and 2 written '
                             'per tile plus 0.59 MB of weights per token and launch' % (tj['launches'], tj['method']))
+        # achieved HBM rate of the whole step: bytes of one step from the committed PMC passes over
+        # this same default workload (scripts/pmc_step_traffic.py) over this run's step time
+        hbm = None
+        spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc_step_traffic.json')
+        if traffic is not None and world == 1 and not a.no_optimizer and not a.torch_adam and os.path.exists(spath):
+            with open(spath) as f:
+                sj = json.load(f)
+            hbm = {'bytes_per_step': sj['hbm_bytes_per_step'], 'achieved_gbps': sj['hbm_bytes_per_step'] / (dt / a.steps) / 1e9,
+                   'peak_gbps': 8000.0, 'frac': sj['hbm_bytes_per_step'] / (dt / a.steps) / 8e12, 'source': sj['method']}
         out = {
             'metric': 'programs/sec (module-net fwd+bwd, whole node)',
             'value': a.batch * world * a.steps / dt,
@@ -253,6 +262,7 @@ def main():
                             'ms_per_step': v['ms'] / max(sampled_steps if n == dominant else extra_steps, 1),
                             'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
                         for n, v in prof.items()},
+            'hbm': hbm,
             'loss': float(loss.detach()),
         }
         if not a.no_cpu_baseline and world == 1:
