@@ -240,11 +240,13 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'executor train step (fwd + cross-entropy + bwd%s%s), bf16 MFMA with fp32 '
-                                   'accumulation, batch %d/GPU, default 117.5 M-parameter ModuleNet, random '
+                                   'accumulation, batch %d/GPU, %s ModuleNet, random '
                                    'well-formed CLEVR-style programs (<=%d nodes, T=%d, mean %.1f nodes), '
                                    'features %s, programs %s'
                                    % (' + RCCL gradient all-reduce' if world > 1 else '',
-                                      '' if a.no_optimizer else (' + torch fused Adam' if a.torch_adam else ' + Adam (vqa_amd.optim.FusedAdam)'), a.batch, a.max_nodes, a.max_len,
+                                      '' if a.no_optimizer else (' + torch fused Adam' if a.torch_adam else ' + Adam (vqa_amd.optim.FusedAdam)'), a.batch,
+                                      'default 117.5 M-parameter' if a.module_dim == 128 else 'module width %d' % a.module_dim,
+                                      a.max_nodes, a.max_len,
                                       float(np.mean(nodes_step)) / a.batch,
                                       '[N,1024,14,14] fp32 resident in HBM' if a.features == 'fp32' else
                                       'rows of a bf16 [R,196,1024] table resident in HBM, read in place',
