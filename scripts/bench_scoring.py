@@ -47,7 +47,11 @@ def batched():
 with torch.no_grad():
     a, b = loop(), batched()
     torch.cuda.synchronize()
-    assert torch.equal(a, b)
+    # tree and classifier conv are bit-identical (scripts/check_scoring_scale.py); the linear layers pick
+    # tile size and split-k by batch size, and a different fp32 summation order can move a bf16
+    # rounding of their activations: equal at small batches, ~2e-4 apart at 4096 programs
+    err = ((a - b).abs().max() / b.abs().max()).item()
+    assert err < 1e-3, err
     res = {}
     for name, fn in (('per_question_calls', loop), ('one_call', batched)):
         for _ in range(2):
@@ -60,5 +64,5 @@ with torch.no_grad():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         res[name] = {'ms': dt * 1e3, 'programs_per_s': M * K / dt}
-print(json.dumps({'questions': M, 'candidates': K, 'nodes_unshared': p_sep.info.num_nodes,
+print(json.dumps({'max_rel_diff': err, 'questions': M, 'candidates': K, 'nodes_unshared': p_sep.info.num_nodes,
                   'nodes_shared': p_sh.info.num_nodes, **res}))
