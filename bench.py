@@ -83,10 +83,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    force_dp = world == 1 and os.environ.get('VQA_BENCH_FORCE_DP') is not None    # diagnostics: the wrapper's own cost
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if force_dp:
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from vqa_amd.module_net import ModuleNet
     vocab = V.make_vocab()
@@ -96,7 +101,7 @@ def main():
     if os.environ.get('VQA_WGRAD_CHUNK'):
         net.wgrad_chunk = int(os.environ['VQA_WGRAD_CHUNK'])
     step_net = net
-    if world > 1:
+    if world > 1 or force_dp:
         from vqa_amd.dp import DataParallelExecutor
         step_net = DataParallelExecutor(net)
     opt = None
@@ -136,7 +141,7 @@ def main():
                 p.grad = None
         loss = loss_fn(step_net(x, prog), ans)
         loss.backward()
-        if world > 1:
+        if world > 1 or force_dp:
             step_net.finish_grad_sync()
         if opt is not None:
             opt.step()
