@@ -72,6 +72,11 @@ def cpu_baseline(vocab, sample):
 
 def main():
     a = parse()
+    # stdout carries exactly one line, the result: whatever libraries print there (RCCL's version
+    # banner at communicator set-up, for one) is sent to stderr instead
+    result_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -274,7 +279,8 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(vocab, a.cpu_sample)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()
 

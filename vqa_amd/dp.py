@@ -81,14 +81,12 @@ class DataParallelExecutor:
             self._works.append(dist.all_reduce(self._presence, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
         return out
 
-    def _on_plan(self, counts, device):
+    def _on_plan(self, counts, device, need_grad):
         """Called by the executor as soon as the batch's programs are parsed (before its forward
         launches): which tokens any rank uses is agreed on here, on a stream of its own, and is in
         host memory long before finish_grad_sync() asks for it - the host never waits for the
         device's backward pass to learn it."""
-        if not torch.is_grad_enabled():
-            return
-        if device.type != 'cuda':
+        if not need_grad or device.type != 'cuda':      # (grad mode is off inside the executor's autograd function)
             return
         if self._aux is None:
             self._aux = torch.cuda.Stream(device)
@@ -181,14 +179,21 @@ class DataParallelExecutor:
                 array.mul_(scale)            # reduced in place as sums
         for k, (array, rows) in enumerate(self._small_groups):     # these travelled in the flat bucket
             off, cnt = self._layout[('group', k)]
-            groups.append((self._flat[off:off + cnt].view(array.shape), rows))
+            array.copy_(self._flat[off:off + cnt].view(array.shape))
+            groups.append((array, rows))
+        # A parameter whose token this rank used already has its row of the array as .grad (autograd
+        # installed it; the reduction was in place): only the others are touched.
+        by_name, token_of = self._by_name, self._token_of
         for array, rows in groups:
+            base, row_bytes = array.data_ptr(), array[0].numel() * array.element_size()
             for n, row in rows.items():
-                ti = self._token_of.get(n)
-                p = self._by_name[n]
-                if ti is not None and present is not None and not present[ti]:
-                    p.grad = None             # unused on every rank
-                else:
+                p = by_name[n]
+                if present is not None and not present[token_of[n]]:
+                    if p.grad is not None:
+                        p.grad = None         # unused on every rank
+                    continue
+                g = p.grad
+                if g is None or g.data_ptr() != base + row * row_bytes:
                     p.grad = array[row].view(p.shape)
         for n, p in self._params:
             if n in self._grouped_names:

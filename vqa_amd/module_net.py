@@ -227,7 +227,7 @@ class ModuleNet(nn.Module):
         # (the tolerance configuration: results within 1e-3 of the reference's fp32 arithmetic)
         self.precision = 'bf16'
         self.grad_ready_hook = None   # set by the data-parallel wrapper: called as (name, grad tensor)
-        self.plan_ready_hook = None   # likewise: (token counts of the batch, device), right after the programs are parsed
+        self.plan_ready_hook = None   # likewise: (token counts of the batch, device, whether a backward pass will follow), right after the programs are parsed
         self.grad_group_hook = None   # likewise: (array [V, ...], {parameter name: row}) per kind of per-token parameter
         self.backward_done_hook = None
         self.last_token_counts = None
@@ -561,7 +561,7 @@ class ModuleNet(nn.Module):
             info = plan.info
             self.last_token_counts = plan.token_counts()
             if self.plan_ready_hook is not None:
-                self.plan_ready_hook(self.last_token_counts, dev)
+                self.plan_ready_hook(self.last_token_counts, dev, need_grad)
             # the forward part of the tile lists goes up now; the backward part is written and sent
             # once the forward launches are enqueued (the host is what the device waits for here)
             nb, bound = info.blob_words, info.blob_words_bound
@@ -695,7 +695,7 @@ class ModuleNet(nn.Module):
         self.used_fns = torch.from_numpy(plan.used_fns()).to(program.device)
         self.last_token_counts = plan.token_counts()
         if self.plan_ready_hook is not None:
-            self.plan_ready_hook(self.last_token_counts, dev)
+            self.plan_ready_hook(self.last_token_counts, dev, need_grad)
         st = _CallState(N=N, plan=plan, f32=True)
         st['pk'] = pk = self._weights_f32(dev)
         st['blob'] = blob = torch.from_numpy(plan.blob()).to(dev)
