@@ -430,3 +430,16 @@ def test_parameter_storage_moves_are_followed(vocab):
         assert not torch.equal(changed, out['b'])
         p.copy_(torch.as_tensor(sd_b[used + '.conv2.weight']))       # in place (version counter moves)
         assert torch.equal(net(x, prog), out['b'])
+
+
+def test_smallest_batches(vocab):
+    """Edge sizes: a single program of a single column (a lone scene token; a unary token whose input
+    is the implicit scene past the end of the row), and one program next to it in a batch of two."""
+    t2i = vocab['program_token_to_idx']
+    dims = small_dims(128)
+    for rows in ([[t2i['scene']]], [[t2i['count']]], [[t2i['union']]], [[t2i['count'], t2i['scene']], [0, 0]]):
+        prog = np.array(rows, dtype=np.int64)
+        n = prog.shape[0]
+        x = synth.synth_features(50 + n, n, dims['feature_dim'])
+        ans = synth.synth_answers(50 + n, n)
+        check_pair(*run_pair(vocab, dims, prog, x, ans, 51))
