@@ -85,6 +85,11 @@ def main():
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run '
                              '--nproc-per-node %d' % (a.gpus, a.gpus))
         a.gpus = world
+    # diagnostics: all ranks on GPU 0 with gloo between them (a one-GPU box cannot host two RCCL
+    # ranks) - exercises this script's multi-rank path; the figures it prints mean nothing
+    rehearse = world > 1 and os.environ.get('VQA_BENCH_REHEARSE_SHARED_GPU') is not None
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
@@ -95,6 +100,23 @@ def main():
         if force_dp:
             os.environ.setdefault('MASTER_PORT', '29533')
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        elif rehearse:
+            dist.init_process_group('gloo')
+            whole = dist.all_reduce
+
+            class _Done:
+                def wait(self):
+                    return True
+
+            def staged(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+                if not t.is_cuda:
+                    return whole(t, op=op, group=group, async_op=async_op)
+                torch.cuda.current_stream().synchronize()
+                h = t.detach().cpu()
+                whole(h, op=op, group=group)
+                t.copy_(h)
+                return _Done() if async_op else None
+            dist.all_reduce = staged
         else:
             dist.init_process_group('nccl', device_id=dev)
 
@@ -277,6 +299,8 @@ def main():
             'hbm': hbm,
             'loss': float(loss.detach()),
         }
+        if rehearse:
+            out['rehearsal'] = 'all ranks on one GPU, gloo through the host: not a measurement'
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(vocab, a.cpu_sample)
         sys.stdout.flush()
