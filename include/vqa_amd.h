@@ -363,6 +363,18 @@ int vqa_adam_fc1(float* p, const float* g, float* m, float* v, void* packed, int
                  float inv_bc2_sqrt, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Feature feed, host side.  The reference's loader reads one saved [1024][14][14] tensor per image
+ * and stacks a batch in its collate step (DataLoader.py:118-119, DataLoader.py:141-166).  Here the
+ * features of a split sit in one table of rows (bf16 [196][C] each) in host memory, and a batch is
+ * gathered into a contiguous (pinned) buffer by `threads` host threads:
+ * out[i] = table[index[i]], rows of row_bytes bytes.  Host pointers only; returns when the copy is
+ * complete.  An index outside [0, table_rows) fails with VQA_EINVAL before anything is written
+ * (the reference raises on a missing file).
+ * ------------------------------------------------------------------------------------------ */
+int vqa_gather_rows(const void* table, int64_t table_rows, int64_t row_bytes, const int64_t* index,
+                    int64_t n, void* out, int32_t threads);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing for the benchmark (no counterpart in the reference).  Every launch of an MFMA
  * kernel whose kind is enabled is bracketed by HIP events on its stream (two event records per
  * launch cost host time: enable only the kinds wanted).  vqa_prof_collect waits for

@@ -56,6 +56,30 @@ def test_shard_errors(tmp_path):
         feed._to_rows(torch.zeros(3, 8, 7, 7))
 
 
+def test_host_gather_matches_fancy_indexing():
+    """vqa_gather_rows is host code (the pinned-buffer gather of HostFeed): any thread count gives
+    table[index], an empty batch is fine, a row outside the table is refused before any write."""
+    from vqa_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(2)
+    for row_bytes, rows in ((6, 40), (401408, 9), (3 << 20, 3)):
+        table = rng.integers(0, 256, (rows, row_bytes), dtype=np.uint8)
+        for n, threads in ((1, 1), (7, 3), (25, 16), (0, 4)):
+            idx = rng.integers(0, rows, n).astype(np.int64)
+            out = np.full((max(n, 1), row_bytes), 0xAB, dtype=np.uint8)
+            _lib.check(lib.vqa_gather_rows(table.ctypes.data, rows, row_bytes, idx.ctypes.data, n, out.ctypes.data, threads))
+            assert np.array_equal(out[:n], table[idx])
+            if n == 0:
+                assert (out == 0xAB).all()
+    table = np.zeros((4, 8), dtype=np.uint8)
+    out = np.full((2, 8), 7, dtype=np.uint8)
+    for bad in (-1, 4):
+        idx = np.array([1, bad], dtype=np.int64)
+        assert lib.vqa_gather_rows(table.ctypes.data, 4, 8, idx.ctypes.data, 2, out.ctypes.data, 2) == 1      # VQA_EINVAL
+        assert b'outside the table' in lib.vqa_last_error()
+        assert (out == 7).all()
+
+
 @pytest.mark.gpu
 def test_resident_rows_and_channels_last_match_fp32_batches(tmp_path):
     """Same logits and same weight gradients, bit for bit, whether the executor gets the loader's fp32
