@@ -1,6 +1,6 @@
-"""Data parallelism end to end on the GPU: two ranks (both on cuda:0, gloo carrying the CUDA
-tensors, since RCCL refuses two ranks on one device) each run the HIP executor on their half of a
-batch; the synchronised gradients must equal those of one process on the whole batch."""
+"""Data parallelism end to end on the GPU: two ranks (both on cuda:0 with gloo between them,
+tests/dp_rig.py, since RCCL refuses two ranks on one device) each run the HIP executor on their half
+of a batch; the synchronised gradients must equal those of one process on the whole batch."""
 import os
 import socket
 
@@ -19,8 +19,8 @@ DIMS = dict(feature_dim=(128, 14, 14), module_dim=128, classifier_proj_dim=128, 
 
 
 def _worker(rank, world, port, n):
-    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import dp_rig
+    dp_rig.join(rank, world, port)
     try:
         from vqa_amd.dp import DataParallelExecutor, shard_rows
         from vqa_amd.module_net import ModuleNet
@@ -53,7 +53,7 @@ def _worker(rank, world, port, n):
             err = ((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-20)).item()
             assert err <= 2e-3, '%s %g' % (k, err)
     finally:
-        dist.destroy_process_group()
+        dp_rig.leave()
 
 
 def test_two_rank_gradients_equal_single_process():

@@ -1,5 +1,5 @@
 """Two data-parallel ranks with the real executor.  A single-GPU box cannot host two RCCL ranks, so
-both processes use cuda:0 and the collectives go over gloo (device tensors staged through the host by the test):
+both processes use cuda:0 and the collectives go over gloo (tests/dp_rig.py):
 what is checked is everything but the transport - the batch split (`Functions.py:122-126`: rows
 [r*N/G, (r+1)*N/G) per replica), the hooks the executor fires during backward, in-place reduction
 of the gradient arrays, which parameters keep `grad is None`, and that the two replicas stay equal.
@@ -66,34 +66,12 @@ def _train(rank, world, out_path):
 
 
 def _rank_main(rank, world, port, out_dir):
-    import faulthandler
-    import torch.distributed as dist
-    faulthandler.dump_traceback_later(90, exit=True)     # a stuck collective names its line instead of hanging the suite
-    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    # gloo's own handling of device tensors (a worker thread copying on streams of its own) stalled
-    # with two processes on one GPU; the transport is not what this test is about, so device tensors
-    # are reduced through the host, in issue order, on the calling thread
-    orig = dist.all_reduce
-
-    class _Done:
-        def wait(self):
-            return True
-
-    def staged(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
-        if not t.is_cuda:
-            return orig(t, op=op, group=group, async_op=async_op)
-        torch.cuda.current_stream().synchronize()
-        h = t.detach().cpu()
-        orig(h, op=op, group=group)
-        t.copy_(h)
-        return _Done() if async_op else None
-    dist.all_reduce = staged
+    import dp_rig
+    dp_rig.join(rank, world, port)
     try:
         _train(rank, world, os.path.join(out_dir, 'rank%d.pt' % rank))
     finally:
-        faulthandler.cancel_dump_traceback_later()
-        dist.destroy_process_group()
+        dp_rig.leave()
 
 
 def test_two_ranks_match_whole_batch_training():
