@@ -443,3 +443,31 @@ def test_smallest_batches(vocab):
         x = synth.synth_features(50 + n, n, dims['feature_dim'])
         ans = synth.synth_answers(50 + n, n)
         check_pair(*run_pair(vocab, dims, prog, x, ans, 51))
+
+
+def test_boundary_accepts_what_the_reference_accepts(vocab):
+    """forward() reads programs through `.item()` in the reference (Module_Model.py:199-200), so any
+    integer dtype, any strides and either device work there; features go through nn.Conv2d, so any
+    memory format does.  All of them must give the same logits here.  An empty batch dies in the
+    reference at torch.cat of nothing (Module_Model.py:232): a RuntimeError here as well."""
+    from vqa_amd.module_net import ModuleNet
+    dims = small_dims(128)
+    net = ModuleNet(False, vocab, **dims)
+    net.load_state_dict(synth.synth_state_dict(3, vocab, **dims))
+    net.cuda().eval()
+    n = 6
+    prog = torch.from_numpy(synth.synth_programs(9, n, vocab, max_len=12, max_nodes=9)).cuda()
+    x = torch.from_numpy(synth.synth_features(9, n, dims['feature_dim'])).cuda()
+    with torch.no_grad():
+        ref = net(x, prog)
+        used = net.used_fns.clone()
+        for p in (prog.to(torch.int32), prog.to(torch.int16), prog.t().contiguous().t(),
+                  torch.stack([prog, prog], 2)[:, :, 0], prog.cpu()):
+            assert torch.equal(net(x, p), ref)
+            assert torch.equal(net.used_fns.cpu(), used.cpu()) and net.used_fns.device == p.device
+        for xx in (x.contiguous(memory_format=torch.channels_last), torch.stack([x, x], 1)[:, 0], x.double()):
+            assert torch.equal(net(xx, prog), ref)
+        with pytest.raises(RuntimeError, match='non-empty list'):
+            net(x[:0], prog[:0])
+        with pytest.raises(AssertionError):
+            net(x, prog[:3])

@@ -372,6 +372,9 @@ class ModuleNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError('vqa_amd.ModuleNet runs on an MI355X only: features must be a CUDA/HIP '
                                'tensor (no CPU fallback)')
+        if N == 0:
+            # the reference gets as far as torch.cat of no module outputs (Module_Model.py:232)
+            raise RuntimeError('torch.cat(): expected a non-empty list of Tensors (empty batch)')
         _lib.load()
         params = [p for _, p in self._param_groups()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
