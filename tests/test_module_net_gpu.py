@@ -469,5 +469,14 @@ def test_boundary_accepts_what_the_reference_accepts(vocab):
             assert torch.equal(net(xx, prog), ref)
         with pytest.raises(RuntimeError, match='non-empty list'):
             net(x[:0], prog[:0])
+        # wrapped as the reference wraps it (Functions.py:124): with one visible GPU DataParallel calls
+        # the module itself; a replica (several GPUs) is refused with a pointer to the process-per-GPU wrapper
+        if torch.cuda.device_count() == 1:
+            assert torch.equal(torch.nn.DataParallel(net)(x, prog), ref)
+        import copy
+        replica = copy.copy(net)
+        replica._is_replica = True
+        with pytest.raises(RuntimeError, match='DataParallelExecutor'):
+            replica(x, prog)
         with pytest.raises(AssertionError):
             net(x, prog[:3])

@@ -372,6 +372,12 @@ class ModuleNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError('vqa_amd.ModuleNet runs on an MI355X only: features must be a CUDA/HIP '
                                'tensor (no CPU fallback)')
+        if getattr(self, '_is_replica', False):
+            # torch.nn.DataParallel over several GPUs (Functions.py:122-126) hands forward() a shallow
+            # copy whose parameters are broadcast views; the executor's packed weights, plans and
+            # workspaces belong to one device
+            raise RuntimeError('vqa_amd.ModuleNet cannot run as a torch.nn.DataParallel replica: run one process '
+                               'per GPU and wrap the executor in vqa_amd.dp.DataParallelExecutor')
         if N == 0:
             # the reference gets as far as torch.cat of no module outputs (Module_Model.py:232)
             raise RuntimeError('torch.cat(): expected a non-empty list of Tensors (empty batch)')
