@@ -239,18 +239,39 @@ __global__ __launch_bounds__(512) void gemm256_kernel(vqa_gemm_params p) {
         const char* la = smem + buf * 4 * GT_BYTES + wm * GT_BYTES;                 // this wave's 128 rows of A
         const char* lb = smem + buf * 4 * GT_BYTES + (2 + (wn >> 1)) * GT_BYTES;    // the image holding its 64 columns
         const int cb = (wn & 1) * 64;
+        // The 8 waves read 96 KB of fragments per 32-deep half of the stage, three quarters of the
+        // time its MFMAs take: read first and multiplied afterwards, the LDS and the MFMA pipe take
+        // turns.  So the second half's fragments are read under the first half's MFMAs: row block mi
+        // of A is multiplied with all four column blocks, then its registers take the second half's
+        // fragment; only B's second half needs registers of its own.
+        bf16x8 af[8], bfr[4], bfr1[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8 af[8], bfr[4];
+        for (int i = 0; i < 8; i++) af[i] = A_KM ? frag_km(la, i * 16, 0, lane) : frag_kc(la, i * 16, 0, lane);
 #pragma unroll
-            for (int i = 0; i < 8; i++) af[i] = A_KM ? frag_km(la, i * 16, ks, lane) : frag_kc(la, i * 16, ks, lane);
+        for (int i = 0; i < 4; i++) bfr[i] = B_KM ? frag_km(lb, cb + i * 16, 0, lane) : frag_kc(lb, cb + i * 16, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) bfr[i] = B_KM ? frag_km(lb, cb + i * 16, ks, lane) : frag_kc(lb, cb + i * 16, ks, lane);
+        for (int mi = 0; mi < 8; mi++) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                for (int mi = 0; mi < 8; mi++) acc[ni][mi] = mma16(bfr[ni], af[mi], acc[ni][mi]);
+            for (int ni = 0; ni < 4; ni++) acc[ni][mi] = mma16(bfr[ni], af[mi], acc[ni][mi]);
+            af[mi] = A_KM ? frag_km(la, mi * 16, 1, lane) : frag_kc(la, mi * 16, 1, lane);
+            if (mi < 4) bfr1[mi] = B_KM ? frag_km(lb, cb + mi * 16, 1, lane) : frag_kc(lb, cb + mi * 16, 1, lane);
         }
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (A_KM ? 2 : 1) + (B_KM ? 2 : 1), 0);
+        }
+#pragma unroll
+        for (int mi = 4; mi < 8; mi++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, A_KM ? 2 : 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 8; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) acc[ni][mi] = mma16(bfr1[ni], af[mi], acc[ni][mi]);
     }
 
     // epilogue: two passes of 128 rows through an fp32 [128][264] LDS tile, whole-row stores
