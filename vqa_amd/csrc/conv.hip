@@ -434,8 +434,10 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
         s = 0;
         conv_kloop<1, true>(halo, xaddr, wbase, 2 * wstep, 4, s, wr, acc, false);
         const int dslot = child ? t.post_dst1 : t.post_dst0, mslot = child ? t.post_mask1 : t.post_mask0;
-        conv_epilogue(halo, acc, nullptr, false, nullptr, mslot >= 0 ? arena + (int64_t)mslot * slot_b : nullptr,
-                      arena + (int64_t)dslot * slot_b, 128, tid);
+        // no bias and no residual are added here, so rounding the accumulators straight into the
+        // image and masking in the row pass gives the same bits as the fp32-staged epilogue, cheaper
+        acc_to_image(halo, acc, nullptr, false, mslot >= 0 ? arena + (int64_t)mslot * slot_b : nullptr,
+                     arena + (int64_t)dslot * slot_b, tid);
     }
     STAMP(7);
 #undef STAMP
