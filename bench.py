@@ -90,6 +90,9 @@ def main():
     rehearse = world > 1 and os.environ.get('VQA_BENCH_REHEARSE_SHARED_GPU') is not None
     if rehearse:
         local = 0
+    ndev = torch.cuda.device_count()
+    if ndev and local >= ndev:
+        local %= ndev            # a launcher that shows each rank only its own GPU(s)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
