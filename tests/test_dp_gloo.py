@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 import torch.nn as nn
 
-from vqa_amd.dp import DataParallelExecutor, shard_rows
+from vqa_amd.dp import DataParallelExecutor, loss_weight, shard_rows
 
 
 class _FakeNet(nn.Module):
@@ -149,3 +149,18 @@ def _worker_grouped(rank, world, port):
 
 def test_grouped_gradients_two_ranks_gloo():
     mp.spawn(_worker_grouped, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_loss_weight_makes_mean_of_shard_means_the_global_mean():
+    g = torch.Generator().manual_seed(4)
+    for n, world in ((10, 4), (16, 4), (7, 8), (1000, 3)):
+        losses = torch.rand(n, generator=g, dtype=torch.float64)
+        acc = 0.0
+        for r in range(world):
+            lo, hi = shard_rows(n, r, world)
+            if hi > lo:
+                acc += loss_weight(n, r, world) * losses[lo:hi].mean().item() / world
+            else:
+                assert loss_weight(n, r, world) == 0.0
+        assert abs(acc - losses.mean().item()) < 1e-12
+    assert loss_weight(16, 2, 4) == 1.0

@@ -33,6 +33,14 @@ def shard_rows(n, rank, world):
     return lo, min(n, lo + per)
 
 
+def loss_weight(n, rank, world):
+    """Factor for a rank's mean loss so that the averaged gradients are those of the mean loss over
+    all `n` samples, as the reference computes it on DataParallel's gathered outputs
+    (Train_model.py:312-314): n_rank * world / n.  It is 1 when `world` divides `n`."""
+    lo, hi = shard_rows(n, rank, world)
+    return (hi - lo) * world / float(n)
+
+
 class DataParallelExecutor:
     def __init__(self, net, process_group=None, direct_bytes=32 << 20):
         if not dist.is_initialized():
