@@ -1,0 +1,33 @@
+"""bench.py's output contract: exactly one JSON line on stdout with the agreed keys, whatever the
+libraries print; a bounded CPU baseline beside it.  Small batch, two steps."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_one_json_line_with_the_agreed_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--batch', '64',
+                        '--batches', '1', '--cpu-sample', '2'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['unit'] == 'programs/s' and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert abs(d['value'] - 64 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    rf = d['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0
+    assert rf['achieved'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    assert rf['traffic'] is None                 # the committed counter passes are of the default workload only
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'programs/s' and cb['sample']
