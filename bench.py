@@ -46,28 +46,47 @@ def parse():
                     help="fp32: the loader's [N,1024,14,14] fp32 batches (default, the reference's input); resident: "
                          'rows of a bf16 feature table held in HBM (vqa_amd.feed.ResidentFeatures), read in place')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=768, help='programs in the CPU baseline sample')
+    ap.add_argument('--cpu-batch', type=int, default=64, help='batch of the CPU baseline (BASELINE config 1: 64)')
+    ap.add_argument('--cpu-reps', type=int, default=3, help='timed repetitions of the CPU baseline')
     return ap.parse_args()
 
 
-def cpu_baseline(vocab, sample):
-    """The CPU restatement of the reference executor (oracle/, per-sample reference order, stock
-    torch fp32 ops) on a bounded sample of the same synthetic workload: forward + loss + backward."""
+def cpu_baseline(vocab, batch, reps):
+    """The CPU restatement of the reference executor (oracle/: per-sample reference order, batch-1
+    stock torch fp32 convolutions, the op sequence of Module_Model.py:196-222) on BASELINE.json's
+    configuration 1: batch 64, fp32, [64,1024,14,14] features, random CLEVR-style programs of <= 27
+    nodes from the generator the GPU run uses.  One warm-up pass, then `reps` timed repetitions each
+    of forward only (no_grad) and of forward + cross-entropy + backward; medians.  Every host core
+    this process may use (the GPU box gives one GPU's share of its cores and says so through
+    OMP_NUM_THREADS)."""
     from oracle.module_net_ref import ModuleNetRef
-    cores = min(16, os.cpu_count() or 1)
+    cores = os.cpu_count() or 1
+    if os.environ.get('OMP_NUM_THREADS', '').isdigit():
+        cores = max(1, min(cores, int(os.environ['OMP_NUM_THREADS'])))
     torch.set_num_threads(cores)
     sd = synth.synth_state_dict(17, vocab)
     ref = ModuleNetRef(vocab, sd)
-    prog = torch.from_numpy(synth.synth_programs(1001, sample, vocab))
-    x = torch.from_numpy(synth.synth_features(1001, sample))
-    ans = torch.from_numpy(synth.synth_answers(1001, sample))
-    ref(x[:2], prog[:2]).sum().backward()        # warm-up
-    t0 = time.perf_counter()
-    torch.nn.functional.cross_entropy(ref(x, prog), ans).backward()
-    dt = time.perf_counter() - t0
-    return {'value': sample / dt, 'unit': 'programs/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d programs of the same synthetic workload, fp32, forward + cross-entropy + '
-                      'backward once (%.1f s)' % (sample, dt)}
+    prog = torch.from_numpy(synth.synth_programs(1001, batch, vocab))
+    x = torch.from_numpy(synth.synth_features(1001, batch))
+    ans = torch.from_numpy(synth.synth_answers(1001, batch))
+    torch.nn.functional.cross_entropy(ref(x[:4], prog[:4]), ans[:4]).backward()        # warm-up
+    fwd, both = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref(x, prog)
+        fwd.append(time.perf_counter() - t0)
+        for p in ref.p.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        torch.nn.functional.cross_entropy(ref(x, prog), ans).backward()
+        both.append(time.perf_counter() - t0)
+    tf, tb = float(np.median(fwd)), float(np.median(both))
+    return {'value': batch / tb, 'unit': 'programs/s', 'cores': cores, 'kind': 'port',
+            'forward_only': batch / tf,
+            'sample': 'BASELINE config 1: batch %d, fp32, default model, programs of <= 27 nodes; 1 warm-up + %d '
+                      'repetitions each of forward only (median %.2f s) and forward + cross-entropy + backward '
+                      '(median %.2f s, `value`)' % (batch, reps, tf, tb)}
 
 
 def main():
@@ -240,6 +259,7 @@ def main():
     if rank == 0:
         idx = [(a.warmup + i) % len(batches) for i in range(a.steps)]
         flops = sum(flops_step[j] for j in idx) / a.steps            # per rank per step (rank 0's batches)
+        flops_exec = sum(flops_exec_step[j] for j in idx)              # per rank, all timed steps
         k = prof[dominant]
         kname = ('resblock_tiles_kernel (fused residual body: two grouped 3x3 implicit-GEMM convolutions per tile, '
                  'forward and input-gradient launches)' if dominant == 'resblock' else
@@ -248,24 +268,42 @@ def main():
         # HBM bytes per launch of the dominant kernel cannot be counted from inside this process: they
         # come from the committed rocprofv3 --pmc passes over this same default workload
         # (scripts/refresh_profiles.sh, scripts/pmc_traffic.py), and only for that workload
-        traffic, traffic_note = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc_resblock_traffic.json')
+        traffic, traffic_note, traffic_src = None, None, None
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+
+        def latest(suffix):
+            """Newest round's committed profile file r<round>_<suffix>, or None."""
+            import glob
+            import re
+            best = None
+            for f in glob.glob(os.path.join(prof_dir, 'r*_' + suffix)):
+                m = re.match(r'r(\d+)_', os.path.basename(f))
+                if m and (best is None or int(m.group(1)) > best[0]):
+                    best = (int(m.group(1)), f)
+            return best[1] if best else None
+
+        def source_of(path, j):
+            return 'committed profile profiles/%s (measured at git %s), not counted in this run' % (
+                os.path.basename(path), j.get('commit', 'unknown'))
+        tpath = latest('pmc_resblock_traffic.json')
         if (dominant == 'resblock' and a.batch == 1024 and a.max_nodes == 27 and a.max_len == 30 and
-                a.features == 'fp32' and os.path.exists(tpath)):
+                a.features == 'fp32' and tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj['hbm_bytes_per_launch']
+            traffic_src = source_of(tpath, tj)
             traffic_note = ('bytes per launch, mean over %d launches; %s; algorithmic: 2-3 maps of 50 176 B read and 2 written '
                             'per tile plus 0.59 MB of weights per token and launch' % (tj['launches'], tj['method']))
         # achieved HBM rate of the whole step: bytes of one step from the committed PMC passes over
         # this same default workload (scripts/pmc_step_traffic.py) over this run's step time
         hbm = None
-        spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc_step_traffic.json')
-        if traffic is not None and world == 1 and not a.no_optimizer and not a.torch_adam and os.path.exists(spath):
+        spath = latest('pmc_step_traffic.json')
+        if traffic is not None and world == 1 and not a.no_optimizer and not a.torch_adam and spath:
             with open(spath) as f:
                 sj = json.load(f)
             hbm = {'bytes_per_step': sj['hbm_bytes_per_step'], 'achieved_gbps': sj['hbm_bytes_per_step'] / (dt / a.steps) / 1e9,
-                   'peak_gbps': 8000.0, 'frac': sj['hbm_bytes_per_step'] / (dt / a.steps) / 8e12, 'source': sj['method']}
+                   'peak_gbps': 8000.0, 'frac': sj['hbm_bytes_per_step'] / (dt / a.steps) / 8e12,
+                   'source': source_of(spath, sj), 'method': sj['method']}
         out = {
             'metric': 'programs/sec (module-net fwd+bwd, whole node)',
             'value': a.batch * world * a.steps / dt,
@@ -287,12 +325,16 @@ def main():
                                       'rows of a bf16 [R,196,1024] table resident in HBM, read in place',
                                       'in host memory' if a.cpu_programs else 'resident in HBM'),
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
+            # executed: what the device runs (the scene nodes of a sample are one computation);
+            # model: what the reference's per-node execution of the same programs would do
+            'executed_tflops': flops_exec * world / dt / 1e12,
             'model_tflops': flops * world * a.steps / dt / 1e12,
-            'executed_tflops': sum(flops_exec_step[j] for j in idx) * world / dt / 1e12,
-            'mfma_peak_frac': flops * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            'mfma_peak_frac': flops_exec / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            'model_flops_frac': flops * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': ach, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
+                         'frac': ach / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'traffic_note': traffic_note,
                          'launches': k['launches'], 'avg_launch_ms': k['ms'] / max(k['launches'], 1),
                          'sampled_steps': sampled_steps},
             'kernels': {n: {'launches': v['launches'],
@@ -305,7 +347,7 @@ def main():
         if rehearse:
             out['rehearsal'] = 'all ranks on one GPU, gloo through the host: not a measurement'
         if not a.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(vocab, a.cpu_sample)
+            out['cpu_baseline'] = cpu_baseline(vocab, a.cpu_batch, a.cpu_reps)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:

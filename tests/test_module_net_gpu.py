@@ -22,7 +22,6 @@ import torch
 import torch.nn.functional as F
 
 from oracle.module_net_ref import ModuleNetRef
-from oracle.make_golden_util import sample_slice
 from vqa_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -131,7 +130,8 @@ def test_fused_and_two_launch_residual_body_identical(vocab):
         out.append((logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
     assert torch.equal(out[0][0], out[1][0])
     assert out[0][1].keys() == out[1][1].keys()
-    # weight gradients are accumulated with fp32 atomics (order varies run to run): tight, not bitwise
+    # bias gradients are accumulated with fp32 atomics (order varies run to run) and the weight gradients'
+    # partial blocks group differently on the two paths: tight, not bitwise
     for k in out[0][1]:
         assert rel(out[0][1][k], out[1][1][k]) <= 1e-5, k
 
@@ -172,8 +172,7 @@ def test_second_step_and_eval_forward_between(vocab):
 
 def test_full_default_against_reference_golden(vocab, golden_dir):
     """Default 117 M-parameter network.  Logits against vectors captured from the reference
-    executor itself; gradients against the bf16-storage oracle at 2e-2, and against the reference's
-    fp32 gradients at the loose bound that bf16 mask flips allow."""
+    executor itself; gradients against the bf16-storage oracle at 2e-2."""
     from vqa_amd.module_net import ModuleNet
     d = np.load(os.path.join(golden_dir, 'full_default.npz'))
     seed, prog = int(d['seed']), d['program']
@@ -200,8 +199,8 @@ def test_full_default_against_reference_golden(vocab, golden_dir):
             assert p.grad is None and rg[k] is None, k
             continue
         assert rel(p.grad, rg[k]) <= TOL, '%s %g' % (k, rel(p.grad, rg[k]))
-        gn = float(d['gnorm/' + k])
-        assert abs(p.grad.double().norm().item() - gn) <= 0.5 * gn, k      # vs fp32 reference: mask flips
+    # free-running gradients against fp32 ones: test_parity_workload_gpu.py (bounded by what bf16 storage
+    # alone does to the oracle); the reference's own gradient goldens are compared with the fp32 path there
 
 
 def test_errors_on_gpu_module(vocab):

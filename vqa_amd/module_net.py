@@ -103,6 +103,7 @@ class _CallState(dict):
         ws = self.pop('ws', None)
         if ws is not None:
             ws.busy = False
+        self['released'] = True
 
     def __del__(self):
         self.release()
@@ -125,8 +126,15 @@ class _ExecFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
-        grads = ctx.net._run_backward(ctx.state, dlogits)
-        return (None, None, None, None, None) + tuple(grads)
+        st = ctx.state
+        if st is None or st.get('released'):
+            # the workspace of this call went back to the pool when its backward ran (or the call was
+            # made without gradients): its maps may already hold another call's values
+            raise RuntimeError('vqa_amd.ModuleNet: backward through a forward call whose buffers were already '
+                               'released (a second backward over the same graph is not supported)')
+        grads = ctx.net._run_backward(st, dlogits, want_dx=ctx.needs_input_grad[1])
+        dx = st.pop('dx', None)
+        return (None, dx, None, None, None) + tuple(grads)
 
 
 class ModuleNet(nn.Module):
@@ -383,7 +391,10 @@ class ModuleNet(nn.Module):
             raise RuntimeError('torch.cat(): expected a non-empty list of Tensors (empty batch)')
         _lib.load()
         params = [p for _, p in self._param_groups()]
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        # the reference's forward is differentiable with respect to the features as well
+        # (Module_Model.py:235-248): x.requires_grad alone asks for a backward pass
+        need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or
+                                                 (not isinstance(x, FeatureRows) and x.requires_grad))
         if isinstance(x, FeatureRows):
             if self.precision != 'bf16':
                 x = x.dense()
@@ -503,7 +514,7 @@ class ModuleNet(nn.Module):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         T = program.size(1)
         ws = self._pool.acquire()
-        st = _CallState(N=N, ws=ws)
+        st = _CallState(N=N, ws=ws, x_dtype=x.dtype if isinstance(x, torch.Tensor) else torch.float32)
         try:
             cur = torch.cuda.current_stream(dev)
             if self._side is None or self._side.device != dev:
@@ -705,7 +716,7 @@ class ModuleNet(nn.Module):
         self.last_token_counts = plan.token_counts()
         if self.plan_ready_hook is not None:
             self.plan_ready_hook(self.last_token_counts, dev, need_grad)
-        st = _CallState(N=N, plan=plan, f32=True)
+        st = _CallState(N=N, plan=plan, f32=True, x_dtype=x.dtype)
         st['pk'] = pk = self._weights_f32(dev)
         st['blob'] = blob = torch.from_numpy(plan.blob()).to(dev)
         slots = info.slots_total if need_grad else info.slots_fwd
@@ -745,7 +756,7 @@ class ModuleNet(nn.Module):
             self.last_state = st
         return st
 
-    def _run_backward_f32(self, st, dlogits):
+    def _run_backward_f32(self, st, dlogits, want_dx=False):
         d = self._dims
         plan, pk, N = st['plan'], st['pk'], st['N']
         dev = dlogits.device
@@ -803,6 +814,8 @@ class ModuleNet(nn.Module):
             grads[tok + '.conv2.weight'], grads[tok + '.conv2.bias'] = gw2[i], acc['gb_conv2'][i]
 
         self._conv(st, arena, arena, pk['wd_stem1'], 'STEM1_DGRAD_TILES', 9, c // 128, c, slot, slot, mask=arena, f32=True)
+        if want_dx:
+            self._input_grad(st, True)
         gs1, gs1b = torch.zeros(1, 9, c, c, **f32), torch.zeros(c, **f32)
         ops.wgrad_tiles(arena, arena, (blob, it_off), it_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), gs1, gs1b,
                         taps=9, k_chunks=c // 128, n_out=c, dw_group_stride=9 * c * c, total_nodes=N, **wg)
@@ -858,9 +871,44 @@ class ModuleNet(nn.Module):
         raise KeyError(kind)
 
     # ------------------------------------------------------------------ backward
-    def _run_backward(self, st, dlogits):
+    def _input_grad(self, st, f32):
+        """d(loss)/d(features) = dgrad_conv0(dS0): the stem's first convolution run backwards over the
+        gradient of its (masked) output, `n_out` = the input channels.  Only computed when the
+        caller's features require a gradient (the reference's callers never do: the features come
+        from the loader, Train_model.py:311).  Leaves st['dx'], [N, Cin, 14, 14] in x's dtype."""
+        d = self._dims
+        plan, N = st['plan'], st['N']
+        c, cin, cpad = d['c'], d['cin'], d['cin_pad']
+        dev = st['arena'].device
+        w = self.stem[0].weight.detach()
+        if cpad != cin:
+            wpad = torch.zeros(c, cpad, 3, 3, dtype=torch.float32, device=dev)
+            wpad[:, :cin] = w
+            w = wpad
+        tiles = np.full((N, 8), -1, dtype=np.int32)
+        tiles[:, 0] = [plan.slot('dS0', i) for i in range(N)]
+        tiles[:, 2] = np.arange(N, dtype=np.int32)
+        tiles[:, 7] = 0
+        tiles = torch.from_numpy(tiles.reshape(-1)).to(dev)
+        geo = dict(taps=9, k_chunks=c // 128, n_out=cpad, src_slot_stride=HW * c, src_pix_stride=c,
+                   dst_slot_stride=HW * cpad, dst_pix_stride=cpad, w_group_stride=0)
+        out = torch.empty(N, cpad, 14, 14, dtype=torch.float32, device=dev)
+        if f32:
+            # [9 taps flipped][k = out channel of the conv][n = its in channel]
+            wd = w.flip(-2, -1).permute(2, 3, 0, 1).reshape(9, c, cpad).contiguous()
+            dxn = torch.empty(N * HW * cpad, dtype=torch.float32, device=dev)
+            ops.conv_tiles(st['arena'], dxn, wd, tiles, N, f32=True, **geo)
+            ops.fc_grad_from_nhwc(dxn, out, N, cpad)
+        else:
+            wd = ops.pack_conv_weight(w.contiguous(), 1, cpad, c, 9, 0, 9, cpad * 9, flip=True)
+            dxn = torch.empty(N * HW * cpad, dtype=torch.bfloat16, device=dev)
+            ops.conv_tiles(st['arena'], dxn, wd, tiles, N, **geo)
+            ops.nhwc_to_nchw(dxn, out, N, cpad)
+        st['dx'] = (out[:, :cin] if cpad != cin else out).to(st['x_dtype'])
+
+    def _run_backward(self, st, dlogits, want_dx=False):
         if st.get('f32'):
-            return self._run_backward_f32(st, dlogits)
+            return self._run_backward_f32(st, dlogits, want_dx)
         d = self._dims
         plan, pk, N = st['plan'], st['pk'], st['N']
         dev = dlogits.device
@@ -986,6 +1034,8 @@ class ModuleNet(nn.Module):
 
         # ---- stem: dS0 = dgrad(dF) * (S0 > 0); weight gradients of both convs (no d/dx)
         self._conv(st, arena, arena, pk['wd_stem1'], 'STEM1_DGRAD_TILES', 9, c // 128, c, slot, slot, mask=arena)
+        if want_dx:
+            self._input_grad(st, False)
         gs1b, gs0b = torch.zeros(c, **f32), torch.zeros(c, **f32)
         fi_off, fi_cnt = plan.section('SAMPLE_ITEMS_FINE')
         ops.wgrad_tiles(arena, arena, (blob, fi_off), fi_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), None, gs1b,
