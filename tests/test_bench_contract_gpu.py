@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_one_json_line_with_the_agreed_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--batch', '64',
-                        '--batches', '1', '--cpu-sample', '2'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        '--batches', '1', '--cpu-batch', '4', '--cpu-reps', '1'], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -31,3 +31,5 @@ def test_one_json_line_with_the_agreed_keys():
     assert rf['traffic'] is None                 # the committed counter passes are of the default workload only
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'programs/s' and cb['sample']
+    assert cb['forward_only'] > cb['value']       # forward alone is reported beside forward + backward
+    assert d['mfma_peak_frac'] <= d['model_flops_frac']      # executed work never exceeds the reference-equivalent count
