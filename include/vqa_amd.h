@@ -280,6 +280,22 @@ int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* items, int32_t 
                      int32_t groups, int32_t n_out, int32_t k_chunks, int32_t taps, float* out,
                      int64_t out_g_stride, void* stream);
 
+/* vqa_wgrad_tiles in partial-block mode followed by vqa_wgrad_reduce, for callers that cannot
+ * allocate device memory or bring a workspace: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference.  The partial blocks live in a
+ * 32 MiB device array that is part of the library (each GPU the library runs on holds its own copy
+ * until the process ends); the call allocates nothing and frees nothing.
+ *   out[group][n][k][tap] = sum over the group's items, as vqa_wgrad_reduce writes it (`groups`
+ *   groups, out_g_stride apart; all of them are written); db is accumulated into as by
+ *   vqa_wgrad_tiles; p->partial and p->dw are ignored.
+ * Limit: num_items * (n_out / 64) * k_chunks * taps <= 1024 partial blocks of 32 KiB, beyond which
+ * the call fails with VQA_EINVAL and a message that says so.  All calls on one GPU share that GPU's
+ * array (it keeps the last call's contents; nothing in it needs clearing between calls), so two
+ * calls that overlap on one GPU (different streams) race: serialise them.  The first call on a
+ * device looks the array's address up (hipGetSymbolAddress): make it outside graph capture. */
+int vqa_wgrad_tiles_noalloc(const vqa_wgrad_params* p, int32_t taps, int32_t groups, float* out,
+                            int64_t out_g_stride, void* stream);
+
 /* dW accumulators [groups][taps][k][n] fp32 -> torch layout [n][k][taps] (OIHW), groups apart by
  * out_g_stride */
 int vqa_unpack_conv_grad(const float* dw, float* out, int32_t groups, int32_t n_out, int32_t k_in,

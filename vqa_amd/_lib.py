@@ -99,6 +99,7 @@ SIGNATURES = {
     'vqa_pack_conv_weight': (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp]),
     'vqa_wgrad_tiles': (i32, [C.POINTER(WgradParams), i32, vp]),
     'vqa_wgrad_reduce': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
+    'vqa_wgrad_tiles_noalloc': (i32, [C.POINTER(WgradParams), i32, i32, vp, i64, vp]),
     'vqa_unpack_conv_grad': (i32, [vp, vp, i32, i32, i32, i32, i64, vp]),
     'vqa_gemm': (i32, [C.POINTER(GemmParams), vp]),
     'vqa_nchw_to_nhwc': (i32, [vp, vp, i32, i32, i32, vp]),

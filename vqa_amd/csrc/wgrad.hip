@@ -22,6 +22,8 @@
 #include "vqa_dev.h"
 #include "plan.h"
 #include "prof.h"
+#include <mutex>
+#include <string>
 
 #define XH_STRIDE 160                        // 64 channels + 32 bytes
 #define XH_POS 264
@@ -293,6 +295,64 @@ extern "C" int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* item
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_wgrad_reduce: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient for callers that cannot allocate (HIP graph capture, tight serving loops): the
+// partial blocks of vqa_wgrad_tiles live in a file-scope device array instead of a caller
+// workspace, and the reduction into torch's layout follows in the same call.  Every GPU the
+// library runs on holds its own copy of the array until the process ends; its address on a device
+// is looked up once, with that device current (the array's name is only a host-side handle).
+// ---------------------------------------------------------------------------------------------
+#define WG_SCRATCH_BLOCKS 1024                                    // blocks of 8192 floats: 32 MiB
+static __device__ __align__(256) float scratch[(size_t)WG_SCRATCH_BLOCKS * 8192];
+#define WG_MAX_DEVICES 64
+static float* g_scratch_ptr[WG_MAX_DEVICES];                      // per device, null until looked up
+static std::mutex g_scratch_mu;
+
+static int wgrad_scratch_on_current_device(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WG_MAX_DEVICES) {
+        vqa_set_error("vqa_wgrad_tiles_noalloc: no current device (or a device index beyond 63)");
+        return VQA_ELAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            vqa_set_error(std::string("vqa_wgrad_tiles_noalloc: hipGetSymbolAddress: ") + hipGetErrorString(e));
+            return VQA_ELAUNCH;
+        }
+        g_scratch_ptr[dev] = (float*)ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return VQA_OK;
+}
+
+extern "C" int vqa_wgrad_tiles_noalloc(const vqa_wgrad_params* p, int32_t taps, int32_t groups, float* out,
+                                       int64_t out_g_stride, void* stream) {
+    if (!p || !out || groups <= 0 || (taps != 9 && taps != 1) || p->num_items < 0 || p->n_out <= 0 ||
+        p->n_out % 64 != 0 || p->k_chunks <= 0) {
+        vqa_set_error("vqa_wgrad_tiles_noalloc: bad argument");
+        return VQA_EINVAL;
+    }
+    // one block of taps * 8192 floats per (item, 64 output channels, 128-channel source chunk)
+    const int64_t need = (int64_t)p->num_items * (p->n_out / 64) * p->k_chunks * taps;
+    if (need > WG_SCRATCH_BLOCKS) {
+        vqa_set_error("vqa_wgrad_tiles_noalloc: " + std::to_string(need) + " partial blocks of 32 KiB needed (items x n_out/64 x "
+                      "k_chunks x taps), the static scratch holds " + std::to_string(WG_SCRATCH_BLOCKS) +
+                      ": split the item list over several calls or use vqa_wgrad_tiles with a workspace");
+        return VQA_EINVAL;
+    }
+    float* sc = nullptr;
+    int rc = wgrad_scratch_on_current_device(&sc);
+    if (rc) return rc;
+    vqa_wgrad_params q = *p;
+    q.partial = sc;          // every block the reduction reads is written whole by this launch: nothing to clear
+    q.dw = nullptr;
+    if ((rc = vqa_wgrad_tiles(&q, taps, stream))) return rc;
+    return vqa_wgrad_reduce(sc, q.items, q.num_items, groups, q.n_out, q.k_chunks, taps, out, out_g_stride, stream);
 }
 
 // dW accumulators [group][tap][k][n] fp32 -> torch's [n][k][tap] per group

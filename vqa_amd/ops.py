@@ -82,12 +82,9 @@ def pack_conv_weight(w, groups, n_out, k_in, taps, g_stride, n_stride, k_stride,
     return out
 
 
-def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps, k_chunks, n_out,
-                src_slot_stride, dy_slot_stride, src_pix_stride, dy_pix_stride, dw_group_stride,
-                src1_slots=None, pair_chunks=0, total_nodes=0, partial=None, f32=False):
-    """items / *_slots are (tensor, word_offset) pairs into an int32 device blob.  With `partial`
-    (fp32 workspace of num_items * n_out/64 * k_chunks * taps * 8192 elements) the workgroups store
-    partial blocks for wgrad_reduce and `dw` may be None; otherwise they add into `dw` atomically."""
+def _wgrad_params(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, k_chunks, n_out,
+                  src_slot_stride, dy_slot_stride, src_pix_stride, dy_pix_stride, dw_group_stride,
+                  src1_slots=None, pair_chunks=0, total_nodes=0):
     p = _lib.WgradParams()
     p.src, p.dy = src.data_ptr(), dy.data_ptr()
     p.items = items[0].data_ptr() + 4 * items[1]
@@ -95,16 +92,31 @@ def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps,
     p.src1_slots = (src1_slots[0].data_ptr() + 4 * src1_slots[1]) if src1_slots is not None else 0
     p.dy_slots = dy_slots[0].data_ptr() + 4 * dy_slots[1]
     p.dw = dw.data_ptr() if dw is not None else 0
-    if partial is not None:
-        assert partial.numel() >= num_items * (n_out // 64) * k_chunks * taps * 8192
-        p.partial = partial.data_ptr()
     p.db = db.data_ptr() if db is not None else 0
     p.src_slot_stride, p.dy_slot_stride, p.dw_group_stride = src_slot_stride, dy_slot_stride, dw_group_stride
     p.src_pix_stride, p.dy_pix_stride = src_pix_stride, dy_pix_stride
     p.k_chunks, p.pair_chunks, p.n_out, p.num_items = k_chunks, pair_chunks, n_out, num_items
     p.total_nodes = total_nodes
+    return p
+
+
+def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps, partial=None, f32=False, **kw):
+    """items / *_slots are (tensor, word_offset) pairs into an int32 device blob.  With `partial`
+    (fp32 workspace of num_items * n_out/64 * k_chunks * taps * 8192 elements) the workgroups store
+    partial blocks for wgrad_reduce and `dw` may be None; otherwise they add into `dw` atomically."""
+    p = _wgrad_params(src, dy, items, num_items, src_slots, dy_slots, dw, db, **kw)
+    if partial is not None:
+        assert partial.numel() >= num_items * (kw['n_out'] // 64) * kw['k_chunks'] * taps * 8192
+        p.partial = partial.data_ptr()
     fn = _lib.load().vqa_wgrad_tiles_f32 if f32 else _lib.load().vqa_wgrad_tiles
     _lib.check(fn(C.byref(p), taps, _stream()))
+
+
+def wgrad_tiles_noalloc(src, dy, items, num_items, src_slots, dy_slots, db, out, *, taps, groups, out_g_stride, **kw):
+    """wgrad_tiles + wgrad_reduce with the partial blocks in the library's own static device array:
+    allocates nothing (vqa_wgrad_tiles_noalloc).  `out` is fp32 [groups][n_out][k][taps]."""
+    p = _wgrad_params(src, dy, items, num_items, src_slots, dy_slots, None, db, **kw)
+    _lib.check(_lib.load().vqa_wgrad_tiles_noalloc(C.byref(p), taps, groups, _ptr(out), out_g_stride, _stream()))
 
 
 def wgrad_reduce(partial, items, num_items, groups, n_out, k_chunks, taps, out, out_g_stride):
