@@ -378,6 +378,20 @@ int vqa_adam_fc1(float* p, const float* g, float* m, float* v, void* packed, int
                  float weight_decay, float beta1, float beta2, float eps, float step_size,
                  float inv_bc2_sqrt, void* stream);
 
+/* The same update for convolution weights [cout][cin][taps] (torch's OIHW, taps flattened; cout and
+ * cin multiples of 128) that also rewrites, per tensor, the packed bf16 copies the convolution
+ * kernels read (vqa_pack_conv_weight's layout): pk_fwd = the forward copy of this tensor's weight
+ * group (n = output channel, k = input channel), pk_bwd = its input-gradient copy (n = input
+ * channel, k = output channel, taps flipped); either may be null.  One launch updates `num_tensors`
+ * tensors of one shape from a device table; saves re-packing every weight after every optimizer step. */
+typedef struct {
+    float* p; const float* g; float* m; float* v;
+    void* pk_fwd; void* pk_bwd;
+    float step_size, inv_bc2_sqrt;
+} vqa_adam_conv_tensor;
+int vqa_adam_conv_pack(const vqa_adam_conv_tensor* tensors, int32_t num_tensors, int32_t cout, int32_t cin,
+                       int32_t taps, float weight_decay, float beta1, float beta2, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Feature feed, host side.  The reference's loader reads one saved [1024][14][14] tensor per image
  * and stacks a batch in its collate step (DataLoader.py:118-119, DataLoader.py:141-166).  Here the

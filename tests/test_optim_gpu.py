@@ -89,3 +89,59 @@ def test_training_with_fused_adam_equals_training_with_torch_adam(vocab):
     moved = ((outs[0][1] - outs[0][0]).norm() / outs[0][0].norm()).item()
     rel = ((outs[0][1] - outs[1][1]).norm() / outs[1][1].norm()).item()
     assert moved > 0.05 and rel <= 5e-3, (moved, rel)
+
+
+@pytest.mark.parametrize('width', [128, 256])
+def test_fused_adam_rewrites_the_packed_convolution_weights(vocab, width):
+    """Once a forward has laid the packed bf16 weight copies out, FusedAdam's update of a convolution
+    weight also rewrites its two packed copies (forward and input-gradient form): they must equal a
+    fresh pack of the updated weights bit for bit, tensors without a gradient must keep theirs, and
+    the next forward (which then skips the re-pack) must give the logits of a freshly loaded executor."""
+    from vqa_amd import ops
+    from vqa_amd.module_net import ModuleNet
+    from vqa_amd.optim import FusedAdam
+    dims = dict(feature_dim=(128, 14, 14), module_dim=width, classifier_proj_dim=width, classifier_fc_layers=(128,))
+    net = ModuleNet(False, vocab, **dims)
+    net.load_state_dict(synth.synth_state_dict(8, vocab, **dims))
+    net.cuda().train()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    prog = torch.from_numpy(synth.synth_programs(90, 6, vocab, max_len=12, max_nodes=9)).cuda()
+    x = torch.from_numpy(synth.synth_features(90, 6, dims['feature_dim'])).cuda()
+    with torch.no_grad():
+        net(x, prog)                                    # lays the packs out
+    opt = FusedAdam(net.parameters(), lr=1e-2, weight_decay=5e-5, executor=net)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    names = [k for k, _ in net.named_parameters()]
+    for step in range(2):
+        skip = set(names[12 + step::5])
+        for k, p in net.named_parameters():
+            p.grad = None if k in skip else torch.randn(p.shape, device='cuda', generator=g) * 0.01
+        opt.step()
+    assert net._conv_packs_fresh
+    c, p_, nv = width, width, len(net._tokens)
+    stk, bufs = net._stacks, net._pack_bufs
+    g33 = c * c * 9
+    s1, cl = net.stem[2].weight.detach(), net.classifier[0].weight.detach()
+    fresh = {
+        'w_conv1': ops.pack_conv_weight(stk['w1'], nv, c, c, 9, g33, c * 9, 9),
+        'w_conv2': ops.pack_conv_weight(stk['w2'], nv, c, c, 9, g33, c * 9, 9),
+        'wd_conv1': ops.pack_conv_weight(stk['w1'], nv, c, c, 9, g33, 9, c * 9, flip=True),
+        'wd_conv2': ops.pack_conv_weight(stk['w2'], nv, c, c, 9, g33, 9, c * 9, flip=True),
+        'w_proj': ops.pack_conv_weight(stk['wp'], nv, c, 2 * c, 1, 2 * c * c, 2 * c, 1),
+        'wd_proj': ops.pack_conv_weight(stk['wp'], nv, 2 * c, c, 1, 2 * c * c, 1, 2 * c),
+        'w_stem1': ops.pack_conv_weight(s1, 1, c, c, 9, 0, c * 9, 9),
+        'wd_stem1': ops.pack_conv_weight(s1, 1, c, c, 9, 0, 9, c * 9, flip=True),
+        'w_cls': ops.pack_conv_weight(cl, 1, p_, c, 1, 0, c, 1),
+        'wd_cls': ops.pack_conv_weight(cl, 1, c, p_, 1, 0, 1, c),
+    }
+    torch.cuda.synchronize()
+    for k, v in fresh.items():
+        assert torch.equal(bufs[k], v), k
+    with torch.no_grad():
+        got = net(x, prog).clone()
+    assert not net._conv_packs_fresh                   # consumed by that forward
+    other = ModuleNet(False, vocab, **dims)
+    other.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    other.cuda().eval()
+    with torch.no_grad():
+        assert torch.equal(got, other(x, prog))

@@ -115,6 +115,7 @@ SIGNATURES = {
     'vqa_adam_tensors': (i32, [vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     'vqa_adam_fc1': (i32, [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                          C.c_float, vp]),
+    'vqa_adam_conv_pack': (i32, [vp, i32, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     'vqa_prof_enable': (i32, [i32]),
     'vqa_prof_collect': (i32, [C.POINTER(C.c_double), i32]),
     'vqa_tree_forward': (i32, [vp, C.POINTER(TreeCtx), vp]),

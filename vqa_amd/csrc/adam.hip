@@ -137,3 +137,107 @@ extern "C" int vqa_adam_fc1(float* p, const float* g, float* m, float* v, void* 
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_adam_fc1: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;
 }
+
+// Convolution weights [cout][cin][taps] fp32 (torch's OIHW with the taps flattened): the Adam update
+// and, in the same pass, the two bf16 fragment-major copies the convolution kernels stream
+// (vqa_pack_conv_weight's layout): the forward one (n = output channel, k = input channel) and the
+// input-gradient one (n = input channel, k = output channel, taps flipped).  Re-packing every
+// weight after every optimizer step otherwise costs a dozen launches and a second trip over them.
+// Block = one tensor x 8 output channels: a contiguous [8][cin * taps] slice of p, g, m, v
+// (16-byte streaming accesses); the updated slice also goes to LDS as bf16, from where each thread
+// assembles 16-byte fragment pieces: 8 consecutive input channels of one (output channel, tap) for
+// the forward copy, the 8 output channels of one (input channel, tap) for the other.
+__global__ __launch_bounds__(256) void adam_conv_pack_kernel(const vqa_adam_conv_tensor* __restrict__ tensors, int cout,
+                                                             int cin, int taps, float wd, float beta1, float beta2,
+                                                             float eps) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t ctile[];     // [8][cin * taps + 8]
+    const vqa_adam_conv_tensor t = tensors[blockIdx.y];
+    const int o0 = blockIdx.x * 8, tid = threadIdx.x;
+    const int row = cin * taps, ld = row + 8;
+    const int64_t base = (int64_t)o0 * row;
+    const int nq = 2 * row;                       // float4 pieces of the slice (8 * row / 4)
+    const float b1c = 1.f - beta1, b2c = 1.f - beta2;
+#pragma unroll 1
+    for (int q0 = 0; q0 < nq; q0 += 3 * 256) {
+        float4 pv[3], gv[3], mv[3], vv[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int q = min(q0 + 256 * i + tid, nq - 1);
+            pv[i] = ntload4(t.p + base + q * 4); gv[i] = ntload4(t.g + base + q * 4);
+            mv[i] = ntload4(t.m + base + q * 4); vv[i] = ntload4(t.v + base + q * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int q = q0 + 256 * i + tid;
+            if (q < nq) {
+                adam1(pv[i].x, gv[i].x, mv[i].x, vv[i].x, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+                adam1(pv[i].y, gv[i].y, mv[i].y, vv[i].y, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+                adam1(pv[i].z, gv[i].z, mv[i].z, vv[i].z, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+                adam1(pv[i].w, gv[i].w, mv[i].w, vv[i].w, wd, b1c, beta2, b2c, t.step_size, t.inv_bc2_sqrt, eps);
+                ntstore4(t.p + base + q * 4, pv[i]); ntstore4(t.m + base + q * 4, mv[i]);
+                ntstore4(t.v + base + q * 4, vv[i]);
+                const int e = q * 4, ol = e / row, r = e - ol * row;     // row % 4 == 0: the four stay in one row
+                uint32_t* d = (uint32_t*)(ctile + ol * ld + r);
+                d[0] = cvt_pk_bf16((f32x2){pv[i].x, pv[i].y});
+                d[1] = cvt_pk_bf16((f32x2){pv[i].z, pv[i].w});
+            }
+        }
+    }
+    __syncthreads();
+    // forward copy: element (n = o, k = ci, tap) sits at
+    // [ci / 128][tap][(ci % 128) / 32][o / 16][lane = o % 16 + 16 * ((ci % 32) / 8)][ci % 8]
+    if (t.pk_fwd) {
+        const int nb16 = cout >> 4;
+        for (int u = tid; u < row; u += 256) {
+            const int ol = u & 7, w = u >> 3;                 // w enumerates (tap, group of 8 input channels)
+            const int cig = w % (cin >> 3), tap = w / (cin >> 3);
+            const int o = o0 + ol;
+            const bf16_t* s = ctile + ol * ld + cig * 8 * taps + tap;
+            uint4 v;
+            v.x = (uint32_t)s[0] | ((uint32_t)s[taps] << 16);
+            v.y = (uint32_t)s[2 * taps] | ((uint32_t)s[3 * taps] << 16);
+            v.z = (uint32_t)s[4 * taps] | ((uint32_t)s[5 * taps] << 16);
+            v.w = (uint32_t)s[6 * taps] | ((uint32_t)s[7 * taps] << 16);
+            const int chunk = cig >> 4, ks = (cig >> 2) & 3, kq = cig & 3;
+            const int64_t idx = ((((int64_t)(chunk * taps + tap) * 4 + ks) * nb16 + (o >> 4)) * 64 + (o & 15) + 16 * kq) * 8;
+            *(uint4*)((bf16_t*)t.pk_fwd + idx) = v;
+        }
+    }
+    // input-gradient copy: element (n = ci, k = o, flipped tap) sits at
+    // [o / 128][taps - 1 - tap][(o % 128) / 32][ci / 16][lane = ci % 16 + 16 * ((o % 32) / 8)][o % 8]
+    if (t.pk_bwd) {
+        const int nb16 = cin >> 4;
+        const int chunk = o0 >> 7, ks = (o0 >> 5) & 3, kq = (o0 >> 3) & 3;
+        for (int u = tid; u < row; u += 256) {
+            const int ci = u % cin, tap = u / cin;
+            const bf16_t* s = ctile + ci * taps + tap;
+            uint4 v;
+            v.x = (uint32_t)s[0] | ((uint32_t)s[ld] << 16);
+            v.y = (uint32_t)s[2 * ld] | ((uint32_t)s[3 * ld] << 16);
+            v.z = (uint32_t)s[4 * ld] | ((uint32_t)s[5 * ld] << 16);
+            v.w = (uint32_t)s[6 * ld] | ((uint32_t)s[7 * ld] << 16);
+            const int64_t idx = ((((int64_t)(chunk * taps + (taps - 1 - tap)) * 4 + ks) * nb16 + (ci >> 4)) * 64 + (ci & 15) + 16 * kq) * 8;
+            *(uint4*)((bf16_t*)t.pk_bwd + idx) = v;
+        }
+    }
+}
+
+extern "C" int vqa_adam_conv_pack(const vqa_adam_conv_tensor* tensors, int32_t num_tensors, int32_t cout, int32_t cin,
+                                  int32_t taps, float weight_decay, float beta1, float beta2, float eps, void* stream) {
+    if (!tensors || num_tensors < 0 || cout <= 0 || cout % 128 != 0 || cin <= 0 || cin % 128 != 0 || taps <= 0 ||
+        (int64_t)(cin * taps + 8) * 16 > 160 * 1024) {
+        vqa_set_error("vqa_adam_conv_pack: bad argument (channel counts must be multiples of 128; 8 x cin x taps bf16 must fit in LDS)");
+        return VQA_EINVAL;
+    }
+    if (num_tensors == 0) return VQA_OK;
+    const int lds = (cin * taps + 8) * 8 * 2;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)adam_conv_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { vqa_set_error(std::string("vqa_adam_conv_pack: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    }
+    hipLaunchKernelGGL(adam_conv_pack_kernel, dim3(cout / 8, num_tensors), dim3(256), lds, (hipStream_t)stream, tensors,
+                       cout, cin, taps, weight_decay, beta1, beta2, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_adam_conv_pack: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}

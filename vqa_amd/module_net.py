@@ -220,6 +220,9 @@ class ModuleNet(nn.Module):
         self._plist = None            # cached _param_groups()
         self._stacks = None           # the per-token parameters' shared [V, ...] arrays
         self._packed = {}
+        self._pack_bufs = {}          # persistent destinations of the packed convolution weights
+        self._pack_targets = None
+        self._conv_packs_fresh = False  # set by vqa_amd.optim.FusedAdam: it rewrote those copies with its update
         self._fc1_packed = None       # persistent bf16 copy of the first linear layer's weight
         self.segment_marks = None     # diagnostics: see _mark
         self._fc1_fresh = False       # set by vqa_amd.optim.FusedAdam: that copy already holds the updated weight
@@ -311,30 +314,43 @@ class ModuleNet(nn.Module):
         key = (ptrs, tuple(p._version for _, p in plist), str(device))
         if key == self._packed_key and not self._packed_stale:
             return self._packed
-        fc1_ready = self._fc1_fresh and key == self._packed_key and self._fc1_packed is not None
-        self._fc1_fresh = False
+        same = key == self._packed_key
+        fc1_ready = self._fc1_fresh and same and self._fc1_packed is not None
+        # vqa_amd.optim.FusedAdam rewrites the packed copies of the convolution weights it updates (all
+        # but the stem's first): nothing to redo for those when nothing else touched the parameters
+        conv_ready = self._conv_packs_fresh and same
+        self._fc1_fresh = self._conv_packs_fresh = False
         self._packed_stale = False
         d = self._dims
         c, p_, cin, cpad = d['c'], d['p'], d['cin'], d['cin_pad']
         nv = len(self._tokens)
-        pk = {}
+        pk = self._packed if same else {}
+        bufs = self._pack_bufs
+
+        def pack(name, *args, **kw):
+            # persistent destinations: the optimizer kernel writes into them between forwards
+            out = bufs.get(name)
+            if out is not None and out.device != device:
+                out = None
+            bufs[name] = pk[name] = ops.pack_conv_weight(*args, out=out, **kw)
         with torch.no_grad():
             f32 = dict(dtype=torch.float32, device=device)
             w1, w2, wp = stk['w1'], stk['w2'], stk['wp']
             pk['b_conv1'], pk['b_conv2'], pk['b_proj'] = stk['b1'], stk['b2'], stk['bp']
             g33 = c * c * 9
-            pk['w_conv1'] = ops.pack_conv_weight(w1, nv, c, c, 9, g33, c * 9, 9)
-            pk['w_conv2'] = ops.pack_conv_weight(w2, nv, c, c, 9, g33, c * 9, 9)
-            pk['wd_conv1'] = ops.pack_conv_weight(w1, nv, c, c, 9, g33, 9, c * 9, flip=True)
-            pk['wd_conv2'] = ops.pack_conv_weight(w2, nv, c, c, 9, g33, 9, c * 9, flip=True)
-            pk['w_proj'] = ops.pack_conv_weight(wp, nv, c, 2 * c, 1, 2 * c * c, 2 * c, 1)
-            pk['wd_proj'] = ops.pack_conv_weight(wp, nv, 2 * c, c, 1, 2 * c * c, 1, 2 * c)
             s0, s1, cl = self.stem[0], self.stem[2], self.classifier[0]
-            pk['w_stem0'] = ops.pack_conv_weight(s0.weight.contiguous(), 1, c, cin, 9, 0, cin * 9, 9)
-            pk['w_stem1'] = ops.pack_conv_weight(s1.weight.contiguous(), 1, c, c, 9, 0, c * 9, 9)
-            pk['wd_stem1'] = ops.pack_conv_weight(s1.weight.contiguous(), 1, c, c, 9, 0, 9, c * 9, flip=True)
-            pk['w_cls'] = ops.pack_conv_weight(cl.weight.contiguous(), 1, p_, c, 1, 0, c, 1)
-            pk['wd_cls'] = ops.pack_conv_weight(cl.weight.contiguous(), 1, c, p_, 1, 0, 1, c)
+            if not conv_ready:
+                pack('w_conv1', w1, nv, c, c, 9, g33, c * 9, 9)
+                pack('w_conv2', w2, nv, c, c, 9, g33, c * 9, 9)
+                pack('wd_conv1', w1, nv, c, c, 9, g33, 9, c * 9, flip=True)
+                pack('wd_conv2', w2, nv, c, c, 9, g33, 9, c * 9, flip=True)
+                pack('w_proj', wp, nv, c, 2 * c, 1, 2 * c * c, 2 * c, 1)
+                pack('wd_proj', wp, nv, 2 * c, c, 1, 2 * c * c, 1, 2 * c)
+                pack('w_stem1', s1.weight.contiguous(), 1, c, c, 9, 0, c * 9, 9)
+                pack('wd_stem1', s1.weight.contiguous(), 1, c, c, 9, 0, 9, c * 9, flip=True)
+                pack('w_cls', cl.weight.contiguous(), 1, p_, c, 1, 0, c, 1)
+                pack('wd_cls', cl.weight.contiguous(), 1, c, p_, 1, 0, 1, c)
+            pack('w_stem0', s0.weight.contiguous(), 1, c, cin, 9, 0, cin * 9, 9)
             pk['b_stem0'], pk['b_stem1'], pk['b_cls'] = s0.bias, s1.bias, cl.bias
             # linear layers: bf16 [out padded to 128][in]; the first one over the flattened map is
             # re-ordered from c*196+hw (Layers.py:42-44) to the channels-last hw*P+c
@@ -355,6 +371,36 @@ class ModuleNet(nn.Module):
             pk['fc_w'] = fcw
         self._packed, self._packed_key = pk, key
         return pk
+
+    def _conv_pack_targets(self):
+        """For vqa_amd.optim.FusedAdam: {parameter data_ptr: (shape class, address of its group in the
+        forward pack, address in the input-gradient pack)} for every convolution weight whose packed
+        copies the optimizer kernel can rewrite (all but the stem's first), plus the shape classes'
+        (cout, cin, taps).  None before the first forward on the device has laid the packs out."""
+        stk, bufs = self._stacks, self._pack_bufs
+        if stk is None or any(k not in bufs for k in ('w_conv1', 'w_conv2', 'wd_conv1', 'wd_conv2', 'w_proj', 'wd_proj',
+                                                      'w_stem1', 'wd_stem1', 'w_cls', 'wd_cls')):
+            return None
+        s1, cl = self.stem[2].weight, self.classifier[0].weight
+        sig = (stk['w1'].data_ptr(), s1.data_ptr(), cl.data_ptr()) + tuple(bufs[k].data_ptr() for k in sorted(bufs))
+        if self._pack_targets is not None and self._pack_targets[0] == sig:
+            return self._pack_targets[1], self._pack_targets[2]
+        d = self._dims
+        c, p_, nv = d['c'], d['p'], len(self._tokens)
+        out = {}
+        row33, rowp = c * c * 9, 2 * c * c                 # elements per token: fp32 weights and packs alike
+        for i in range(nv):
+            for w, f, b in (('w1', 'w_conv1', 'wd_conv1'), ('w2', 'w_conv2', 'wd_conv2')):
+                out[stk[w].data_ptr() + 4 * i * row33] = ('c33', bufs[f].data_ptr() + 2 * i * row33, bufs[b].data_ptr() + 2 * i * row33)
+            if self._binary[i]:
+                out[stk['wp'].data_ptr() + 4 * i * rowp] = ('proj', bufs['w_proj'].data_ptr() + 2 * i * rowp,
+                                                            bufs['wd_proj'].data_ptr() + 2 * i * rowp)
+        if s1.is_contiguous() and cl.is_contiguous():
+            out[s1.data_ptr()] = ('c33', bufs['w_stem1'].data_ptr(), bufs['wd_stem1'].data_ptr())
+            out[cl.data_ptr()] = ('cls', bufs['w_cls'].data_ptr(), bufs['wd_cls'].data_ptr())
+        shapes = {'c33': (c, c, 9), 'proj': (c, 2 * c, 1), 'cls': (p_, c, 1)}
+        self._pack_targets = (sig, out, shapes)
+        return out, shapes
 
     def _fc1_packed_buffer(self, device):
         lin = self.classifier[self._fc_idx[0]]

@@ -19,6 +19,8 @@ from . import _lib
 _TENSOR = np.dtype([('p', 'u8'), ('g', 'u8'), ('m', 'u8'), ('v', 'u8'), ('numel', 'i8'),
                     ('step_size', 'f4'), ('inv_bc2_sqrt', 'f4')])
 _CHUNK = np.dtype([('tensor', 'i4'), ('pad', 'i4'), ('offset', 'i8')])
+_CONV = np.dtype([('p', 'u8'), ('g', 'u8'), ('m', 'u8'), ('v', 'u8'), ('pk_fwd', 'u8'), ('pk_bwd', 'u8'),
+                  ('step_size', 'f4'), ('inv_bc2_sqrt', 'f4')])
 _CHUNK_ELEMS = 4096
 
 
@@ -32,10 +34,11 @@ class FusedAdam(torch.optim.Optimizer):
         self._recs = {}          # group index -> per-parameter records (see _records)
         self._chunks_key, self._chunks = None, None
 
-    def _tables(self, dev, nbytes):
-        """Two pinned/device buffer pairs per device, used alternately: the host may write the next
-        step's tables while the previous upload is still queued."""
-        ents = self._host.setdefault(dev, [None, None, 0])
+    def _tables(self, key, nbytes):
+        """Two pinned/device buffer pairs per device (and table kind), used alternately: the host may
+        write the next step's tables while the previous upload is still queued."""
+        dev = key[0] if isinstance(key, tuple) else key
+        ents = self._host.setdefault(key, [None, None, 0])
         k = ents[2] = ents[2] ^ 1
         ent = ents[k]
         if ent is None or ent[0].numel() < nbytes:
@@ -78,18 +81,25 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         ex = self._executor
-        fc1 = None
+        fc1, targets, shapes = None, None, None
         if ex is not None and getattr(ex, 'precision', None) == 'bf16':
             fc1 = ex.classifier[ex._fc_idx[0]].weight
+            tg = ex._conv_pack_targets()
+            if tg is not None:
+                targets, shapes = tg
+        managed = 0              # convolution weights with packed copies that this optimizer owns
         f32 = torch.float32
         for gi, group in enumerate(self.param_groups):
             lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
             scale = {}           # step count -> (step_size, 1 / sqrt(bias correction 2))
             by_dev = {}          # device -> column lists of the tensor table
+            conv = {}            # (device, shape class) -> rows of the convolution-weight table
             keep = []
             for idx, r in enumerate(self._records(gi, group)):
                 p = r[0]
                 g = p.grad
+                tgt = targets.get(p.data_ptr()) if targets is not None else None
+                managed += tgt is not None
                 if g is None:
                     continue          # unused token this step: no update, no step count (as torch)
                 if g.dtype != f32 or g.is_sparse:
@@ -118,6 +128,12 @@ class FusedAdam(torch.optim.Optimizer):
                                                 wd, b1, b2, eps, sc[0], sc[1],
                                                 torch.cuda.current_stream(p.device).cuda_stream))
                     ex._fc1_fresh = True
+                    keep.append(g)
+                    continue
+                if tgt is not None:
+                    # a convolution weight: its update also rewrites the packed copies the kernels read
+                    conv.setdefault((p.device, tgt[0]), []).append(
+                        (p.data_ptr(), g.data_ptr(), r[4], r[5], tgt[1], tgt[2], sc[0], sc[1]))
                     keep.append(g)
                     continue
                 cols = by_dev.get(p.device)
@@ -151,5 +167,23 @@ class FusedAdam(torch.optim.Optimizer):
                 ent[2].record(stream)
                 _lib.check(lib.vqa_adam_tensors(devbuf.data_ptr(), devbuf.data_ptr() + off, len(cb) // _CHUNK.itemsize,
                                                 wd, b1, b2, eps, stream.cuda_stream))
+            for (dev, kind), rows in conv.items():
+                n = len(rows)
+                ent = self._tables((dev, kind), n * _CONV.itemsize)
+                tt = ent[3][:n * _CONV.itemsize].view(_CONV)
+                for j, name in enumerate(_CONV.names):
+                    tt[name] = [row[j] for row in rows]
+                stream = torch.cuda.current_stream(dev)
+                ent[1][:n * _CONV.itemsize].copy_(ent[0][:n * _CONV.itemsize], non_blocking=True)
+                ent[2] = torch.cuda.Event()
+                ent[2].record(stream)
+                cout, cin, taps = shapes[kind]
+                _lib.check(lib.vqa_adam_conv_pack(ent[1].data_ptr(), n, cout, cin, taps, wd, b1, b2, eps, stream.cuda_stream))
             self._keep = keep            # gradients stay referenced until the next step (kernels still queued)
+        if ex is not None:
+            ex._packed_stale = True      # parameters changed without their version counters moving
+        if targets is not None and managed == len(targets):
+            # every packed convolution weight belongs to this optimizer: the copies now hold this
+            # step's values (tensors without a gradient did not change)
+            ex._conv_packs_fresh = True
         return loss
