@@ -14,7 +14,7 @@
 
 #define GT_BYTES 16384   // one operand stage: 128 x 64 bf16
 #define GT_STAGES 2      // operand stages in LDS (with the epilogue tile 68 KB: two workgroups per CU; 4 stages at one per CU ran 1.7x slower)
-#define GT_STAGE_LD 136  // row stride (floats) of the epilogue's fp32 staging tile
+#define GT_STAGE_LD 132  // row stride (floats) of the epilogue's fp32 staging tile: 132 % 32 = 4 keeps the 16-byte accumulator writes of 8 rows on 32 different banks (136 made them 2-way conflicts)
 
 // k-contiguous tile [128 rows][64 k]: 16-B chunk j of row r lives at chunk position j ^ (r & 7)
 __device__ __forceinline__ void stage_kc(const char* base, int64_t ld_bytes, char* lds, int lane, int wave) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(vqa_gemm_params p) {
 // near 650 TFLOP/s whatever else is done; a 256 x 256 tile needs half the bytes.  Each operand tile
 // is two of the 128-row images above, staged by one half of the waves each.  M and N must be
 // multiples of 256 (the operand loads are not guarded).
-#define GB_STAGE_LD 264     // row stride (floats) of the epilogue's fp32 [128][256] staging tile
+#define GB_STAGE_LD 260     // row stride (floats) of the epilogue's fp32 [128][256] staging tile (260 % 32 = 4: conflict-free 16-byte writes)
 template <bool A_KM, bool B_KM>
 __global__ __launch_bounds__(512) void gemm256_kernel(vqa_gemm_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,6 +279,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(vqa_gemm_params p) {
     float* cbase = (float*)p.c + (int64_t)kz * p.M * p.ldc;   // split-k slab (fp32 results)
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
+        // the mask rows this thread needs in this pass: all eight loads are in flight across the two
+        // barriers and the staging writes (one at a time in front of each store, their latency was
+        // four HBM round trips per pass)
+        u16x8 mk8[8];
+        if (p.out_mode == 2 && p.mask) {
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int r = it * 16 + wave * 2 + (lane >> 5);
+                mk8[it] = __builtin_nontemporal_load((const u16x8*)((const bf16_t*)p.mask +
+                                                     (int64_t)(m0 + pass * 128 + r) * p.ldc + n0 + (lane & 31) * 8));
+            }
+        }
         __syncthreads();                   // operand stages / the previous pass are done with
         if (wm == pass) {
 #pragma unroll
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(vqa_gemm_params p) {
         const int mbase = m0 + pass * 128;
         if (p.out_mode == 2) {
             const int cg = (lane & 31) * 8;            // 8 columns per lane, 32 lanes per row
-#pragma unroll 2
+#pragma unroll
             for (int it = 0; it < 8; it++) {
                 const int r = it * 16 + wave * 2 + (lane >> 5);
                 const float* sp = stage + r * GB_STAGE_LD + cg;
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(vqa_gemm_params p) {
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 const int64_t off = (int64_t)(mbase + r) * p.ldc + n0 + cg;
                 if (p.mask) {
-                    const u16x8 k8 = *(const u16x8*)((const bf16_t*)p.mask + off);
+                    const u16x8 k8 = mk8[it];
 #pragma unroll
                     for (int q = 0; q < 8; q++) v[q] = ((int16_t)k8[q] > 0) ? v[q] : 0.f;
                 }

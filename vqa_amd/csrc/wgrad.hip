@@ -253,30 +253,67 @@ extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* st
 }
 
 // Sum the partial blocks of vqa_wgrad_tiles per weight group, writing torch's [n][k][tap] layout.
-// A thread owns one (output channel, source channel) pair and all taps; the threads of a block
-// share the group, so the scan over the item list is uniform.
-template <int TAPS>
+// A thread owns one output channel x 4 consecutive source channels x all taps: 16-byte loads from
+// every block, TAPS x 16 contiguous bytes of output.  The pass is all load latency (each partial is
+// read once, from HBM), so the blocks of the group are first listed in LDS - in item order, which
+// fixes the order of the fp32 sums whatever the launch looks like - and then read U at a time.
+template <int TAPS, int U>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const vqa_wgrad_item* __restrict__ items, int num_items,
                                                            int n_out, int k_chunks, float* __restrict__ out,
                                                            int64_t out_g_stride) {
+    __shared__ int list[256];
+    __shared__ int wcount[4];
+    typedef float f32x4r __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = blockIdx.y, k_in = k_chunks * 128;
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // oc * k_in + i
-    const int oc = idx / k_in, i = idx - oc * k_in;
+    const int e = (blockIdx.x * 256 + tid) * 4;              // oc * k_in + i, i a multiple of 4
+    const int oc = e / k_in, i = e - oc * k_in;
     const int oslice = oc >> 6, ocl = oc & 63, kchunk = i >> 7, il = i & 127;
     const int oslices = n_out >> 6;
-    float acc[TAPS];
+    const int64_t in_block = (int64_t)(oslice * k_chunks + kchunk) * (TAPS * 8192) + ocl * 128 + il;
+    const int64_t item_stride = (int64_t)oslices * k_chunks * (TAPS * 8192);
+    f32x4r acc[TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; t++) acc[t] = 0.f;
-    for (int j = 0; j < num_items; j++) {
-        if (items[j].group != grp) continue;
-        const float* part = partial + ((int64_t)(j * oslices + oslice) * k_chunks + kchunk) * (TAPS * 8192) + ocl * 128 + il;
+    for (int t = 0; t < TAPS; t++) acc[t] = (f32x4r){0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < num_items; base += 256) {
+        const int j = base + tid;
+        const bool mine = j < num_items && items[j].group == grp;
+        const unsigned long long b = __ballot(mine);
+        if (lane == 0) wcount[wave] = __popcll(b);
+        __syncthreads();
+        int off = 0, n = 0;
 #pragma unroll
-        for (int t = 0; t < TAPS; t++) acc[t] += __builtin_nontemporal_load(part + t * 8192);   // each partial is read once
+        for (int w = 0; w < 4; w++) { if (w < wave) off += wcount[w]; n += wcount[w]; }
+        if (mine) list[off + __popcll(b & ((1ull << lane) - 1))] = j;
+        __syncthreads();
+        for (int k = 0; k < n; k += U) {
+            f32x4r v[U][TAPS];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (k + u < n) {
+                    const float* part = partial + list[k + u] * item_stride + in_block;
+#pragma unroll
+                    for (int t = 0; t < TAPS; t++) v[u][t] = __builtin_nontemporal_load((const f32x4r*)(part + t * 8192));
+                }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (k + u < n) {
+#pragma unroll
+                    for (int t = 0; t < TAPS; t++) acc[t] += v[u][t];
+                }
+        }
+        __syncthreads();       // the list is rewritten by the next window
     }
-    float* o = out + (int64_t)grp * out_g_stride + (int64_t)idx * TAPS;
+    // (source channel q, tap t) of this thread's 4 x TAPS contiguous outputs is acc[t][q]
+    float* o = out + (int64_t)grp * out_g_stride + (int64_t)e * TAPS;
 #pragma unroll
-    for (int t = 0; t < TAPS; t++) o[t] = acc[t];
+    for (int f = 0; f < TAPS; f++) {
+        f32x4r w;
+#pragma unroll
+        for (int r = 0; r < 4; r++) w[r] = acc[(4 * f + r) % TAPS][(4 * f + r) / TAPS];
+        *(f32x4r*)(o + 4 * f) = w;
+    }
 }
 
 extern "C" int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* items, int32_t num_items,
@@ -287,10 +324,10 @@ extern "C" int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* item
         vqa_set_error("vqa_wgrad_reduce: bad argument");
         return VQA_EINVAL;
     }
-    dim3 grid(n_out * k_chunks * 128 / 256, groups), block(256);
-    if (taps == 9) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, grid, block, 0, (hipStream_t)stream, partial, items,
+    dim3 grid(n_out * k_chunks * 128 / 1024, groups), block(256);      // n_out % 64 == 0: whole blocks
+    if (taps == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<9, 3>), grid, block, 0, (hipStream_t)stream, partial, items,
                                       num_items, n_out, k_chunks, out, out_g_stride);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, grid, block, 0, (hipStream_t)stream, partial, items,
+    else hipLaunchKernelGGL((wgrad_reduce_kernel<1, 8>), grid, block, 0, (hipStream_t)stream, partial, items,
                             num_items, n_out, k_chunks, out, out_g_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_wgrad_reduce: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
