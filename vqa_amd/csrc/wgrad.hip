@@ -257,17 +257,24 @@ extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* st
 // every block, TAPS x 16 contiguous bytes of output.  The pass is all load latency (each partial is
 // read once, from HBM), so the blocks of the group are first listed in LDS - in item order, which
 // fixes the order of the fp32 sums whatever the launch looks like - and then read U at a time.
-template <int TAPS, int U>
+// With SEG > 1 (few groups: the stem and classifier convolutions have one, and a grid of
+// outputs / 1024 workgroups would leave the device idle behind long chains of dependent loads) the
+// workgroup covers 256 / SEG columns and its SEG thread rows each take every SEG-th batch of U
+// blocks; their sums are added through LDS in row order.
+template <int TAPS, int U, int SEG>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const vqa_wgrad_item* __restrict__ items, int num_items,
                                                            int n_out, int k_chunks, float* __restrict__ out,
                                                            int64_t out_g_stride) {
+    typedef float f32x4r __attribute__((ext_vector_type(4)));
+    constexpr int COLS = 256 / SEG;
     __shared__ int list[256];
     __shared__ int wcount[4];
-    typedef float f32x4r __attribute__((ext_vector_type(4)));
+    __shared__ f32x4r segsum[SEG > 1 ? (SEG - 1) * COLS * TAPS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = tid % COLS, seg = tid / COLS;
     const int grp = blockIdx.y, k_in = k_chunks * 128;
-    const int e = (blockIdx.x * 256 + tid) * 4;              // oc * k_in + i, i a multiple of 4
+    const int e = (blockIdx.x * COLS + col) * 4;             // oc * k_in + i, i a multiple of 4
     const int oc = e / k_in, i = e - oc * k_in;
     const int oslice = oc >> 6, ocl = oc & 63, kchunk = i >> 7, il = i & 127;
     const int oslices = n_out >> 6;
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int w = 0; w < 4; w++) { if (w < wave) off += wcount[w]; n += wcount[w]; }
         if (mine) list[off + __popcll(b & ((1ull << lane) - 1))] = j;
         __syncthreads();
-        for (int k = 0; k < n; k += U) {
+        for (int k = seg * U; k < n; k += SEG * U) {
             f32x4r v[U][TAPS];
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -304,6 +311,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 }
         }
         __syncthreads();       // the list is rewritten by the next window
+    }
+    if (SEG > 1) {
+        if (seg > 0) {
+#pragma unroll
+            for (int t = 0; t < TAPS; t++) segsum[((seg - 1) * TAPS + t) * COLS + col] = acc[t];
+        }
+        __syncthreads();
+        if (seg > 0) return;
+#pragma unroll
+        for (int s_ = 0; s_ < SEG - 1; s_++)
+#pragma unroll
+            for (int t = 0; t < TAPS; t++) acc[t] += segsum[(s_ * TAPS + t) * COLS + col];
     }
     // (source channel q, tap t) of this thread's 4 x TAPS contiguous outputs is acc[t][q]
     float* o = out + (int64_t)grp * out_g_stride + (int64_t)e * TAPS;
@@ -324,11 +343,18 @@ extern "C" int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* item
         vqa_set_error("vqa_wgrad_reduce: bad argument");
         return VQA_EINVAL;
     }
-    dim3 grid(n_out * k_chunks * 128 / 1024, groups), block(256);      // n_out % 64 == 0: whole blocks
-    if (taps == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<9, 3>), grid, block, 0, (hipStream_t)stream, partial, items,
-                                      num_items, n_out, k_chunks, out, out_g_stride);
-    else hipLaunchKernelGGL((wgrad_reduce_kernel<1, 8>), grid, block, 0, (hipStream_t)stream, partial, items,
-                            num_items, n_out, k_chunks, out, out_g_stride);
+    const int cols4 = n_out * k_chunks * 128 / 4;                  // 16-byte columns per group; n_out % 64 == 0
+    dim3 block(256);
+    hipStream_t s = (hipStream_t)stream;
+    // (single-tap blocks are small: there the plain form is as fast, measured)
+    if (taps == 1 || (int64_t)(cols4 / 256) * groups >= 512) {
+        dim3 grid(cols4 / 256, groups);
+        if (taps == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<9, 3, 1>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride);
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<1, 8, 1>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride);
+    } else {
+        dim3 grid(cols4 / 32, groups);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<9, 2, 8>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_wgrad_reduce: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;
