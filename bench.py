@@ -45,6 +45,9 @@ def parse():
     ap.add_argument('--features', choices=['fp32', 'resident'], default='fp32',
                     help="fp32: the loader's [N,1024,14,14] fp32 batches (default, the reference's input); resident: "
                          'rows of a bf16 feature table held in HBM (vqa_amd.feed.ResidentFeatures), read in place')
+    ap.add_argument('--dp-transport', choices=['fp32', 'bf16'], default='fp32',
+                    help="how the first linear layer's 411 MB gradient crosses the links (N > 1)")
+    ap.add_argument('--dp-algo', choices=['all_reduce', 'reduce_scatter'], default='all_reduce')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=64, help='batch of the CPU baseline (BASELINE config 1: 64)')
     ap.add_argument('--cpu-reps', type=int, default=3, help='timed repetitions of the CPU baseline')
@@ -152,7 +155,7 @@ def main():
     step_net = net
     if world > 1 or force_dp:
         from vqa_amd.dp import DataParallelExecutor
-        step_net = DataParallelExecutor(net)
+        step_net = DataParallelExecutor(net, big_transport=a.dp_transport, big_algo=a.dp_algo)
     opt = None
     if not a.no_optimizer:
         # Train_model.py:165-167: Adam, lr 1e-4, weight_decay 5e-5
@@ -316,7 +319,7 @@ def main():
                                    'accumulation, batch %d/GPU, %s ModuleNet, random '
                                    'well-formed CLEVR-style programs (<=%d nodes, T=%d, mean %.1f nodes), '
                                    'features %s, programs %s'
-                                   % (' + RCCL gradient all-reduce' if world > 1 else '',
+                                   % ((' + RCCL gradient all-reduce (large gradient: %s, %s)' % (a.dp_transport, a.dp_algo)) if world > 1 else '',
                                       '' if a.no_optimizer else (' + torch fused Adam' if a.torch_adam else ' + Adam (vqa_amd.optim.FusedAdam)'), a.batch,
                                       'default 117.5 M-parameter' if a.module_dim == 128 else 'module width %d' % a.module_dim,
                                       a.max_nodes, a.max_len,

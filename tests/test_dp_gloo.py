@@ -164,3 +164,39 @@ def test_loss_weight_makes_mean_of_shard_means_the_global_mean():
                 assert loss_weight(n, r, world) == 0.0
         assert abs(acc - losses.mean().item()) < 1e-12
     assert loss_weight(16, 2, 4) == 1.0
+
+
+def _worker_big_modes(rank, world, port):
+    """The large gradient through every transport/algorithm pair: the averaged result must be the
+    mean of the ranks' gradients - to fp32 rounding on fp32 transport, to bf16 rounding (2^-8
+    relative per element) on bf16 transport - and a second step must reuse the staging buffers."""
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        for transport in ('fp32', 'bf16'):
+            for algo in ('all_reduce', 'reduce_scatter'):
+                net = _FakeNet()
+                dp = DataParallelExecutor(net, direct_bytes=64 * 64 * 4, big_transport=transport, big_algo=algo)
+                for step in range(2):
+                    net.last_token_counts = [1, 1, 0]
+                    dp(torch.zeros(1), None)
+                    gens = [torch.Generator().manual_seed(100 * step + r) for r in range(world)]
+                    every = [torch.randn(64, 64, generator=g) for g in gens]
+                    want = sum(every) / world
+                    net.fake_backward({'classifier.3.weight': every[rank].clone(),
+                                       'scene.conv1.weight': torch.full((4, 3), float(rank)),
+                                       '<NULL>.conv1.weight': torch.ones(4, 3)})
+                    dp.finish_grad_sync()
+                    got = net.big.grad
+                    assert got.dtype == torch.float32 and got.shape == (64, 64)
+                    err = ((got - want).norm() / want.norm()).item()
+                    assert err <= (1e-6 if transport == 'fp32' else 1e-2), (transport, algo, step, err)
+                    if transport == 'bf16':
+                        assert err > 1e-5          # it did cross as bf16
+                    assert torch.allclose(net.mods['scene'].grad, torch.full((4, 3), 0.5))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_large_gradient_transports_and_algorithms_two_ranks_gloo():
+    mp.spawn(_worker_big_modes, args=(2, _free_port()), nprocs=2, join=True)

@@ -28,11 +28,16 @@ def test_single_rank_rccl_matches_plain_training(vocab):
         dims = dict(feature_dim=(128, 14, 14), module_dim=128, classifier_proj_dim=128, classifier_fc_layers=(128,))
         sd = synth.synth_state_dict(41, vocab, **dims)
         runs = []
-        for wrapped in (False, True):
+        for wrapped in (False, True, ('bf16', 'reduce_scatter')):
             net = ModuleNet(False, vocab, **dims)
             net.load_state_dict(sd)
             net.to(dev).train()
-            step_net = DataParallelExecutor(net, direct_bytes=1 << 20) if wrapped else net
+            if wrapped is True:
+                step_net = DataParallelExecutor(net, direct_bytes=1 << 20)
+            elif wrapped:      # the large gradient as a bf16 copy through RCCL's reduce-scatter + all-gather
+                step_net = DataParallelExecutor(net, direct_bytes=1 << 20, big_transport=wrapped[0], big_algo=wrapped[1])
+            else:
+                step_net = net
             opt = FusedAdam(net.parameters(), lr=1e-3, weight_decay=5e-5, executor=net)
             losses = []
             for step in range(3):
@@ -49,7 +54,10 @@ def test_single_rank_rccl_matches_plain_training(vocab):
                 losses.append(loss.item())
             torch.cuda.synchronize()
             runs.append((losses, unused, {k: v.detach().clone() for k, v in net.state_dict().items()}))
-        (la, ua, sa), (lb, ub, sb) = runs
+        (la, ua, sa), (lb, ub, sb), (lc, uc, sc) = runs
+        assert uc == ua
+        for a, c in zip(la, lc):       # one bf16 rounding of one gradient: the trajectory moves by less than bf16 noise
+            assert abs(a - c) <= 5e-3 * max(1.0, abs(a)), (la, lc)
         assert ua == ub and len(ua) > 0                      # tokens no program used keep grad None either way
         for a, b in zip(la, lb):
             assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (la, lb)

@@ -28,7 +28,7 @@ def _batch(step, dev):
     return prog.to(dev), x.to(dev), ans.to(dev)
 
 
-def _train(rank, world, out_path):
+def _train(rank, world, out_path, big=('fp32', 'all_reduce')):
     """Runs STEPS steps on this rank's rows; returns (losses, step-1 gradients, final parameters)."""
     import torch.distributed as dist
     from vqa_amd.dp import DataParallelExecutor, shard_rows
@@ -39,7 +39,8 @@ def _train(rank, world, out_path):
     net = ModuleNet(False, vocab, **DIMS)
     net.load_state_dict(synth.synth_state_dict(43, vocab, **DIMS))
     net.to(dev).train()
-    step_net = DataParallelExecutor(net, direct_bytes=1 << 20) if world > 1 else net
+    step_net = (DataParallelExecutor(net, direct_bytes=1 << 20, big_transport=big[0], big_algo=big[1])
+                if world > 1 else net)
     opt = FusedAdam(net.parameters(), lr=1e-3, weight_decay=5e-5, executor=net)
     lo, hi = shard_rows(BATCH, rank, world)
     losses, first_grads = [], None
@@ -65,20 +66,23 @@ def _train(rank, world, out_path):
     return res
 
 
-def _rank_main(rank, world, port, out_dir):
+def _rank_main(rank, world, port, out_dir, big):
     import dp_rig
     dp_rig.join(rank, world, port)
     try:
-        _train(rank, world, os.path.join(out_dir, 'rank%d.pt' % rank))
+        _train(rank, world, os.path.join(out_dir, 'rank%d.pt' % rank), big)
     finally:
         dp_rig.leave()
 
 
-def test_two_ranks_match_whole_batch_training():
+@pytest.mark.parametrize('big', [('fp32', 'all_reduce'), ('bf16', 'reduce_scatter')])
+def test_two_ranks_match_whole_batch_training(big):
+    """big: how the first linear layer's gradient (the one above direct_bytes) crosses: fp32 all-reduce,
+    or a bf16 copy through reduce-scatter + all-gather (within the bf16 path's gradient tolerance)."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_rank_main, args=(2, port, d), nprocs=2, join=True)
+        mp.spawn(_rank_main, args=(2, port, d, big), nprocs=2, join=True)
         r0 = torch.load(os.path.join(d, 'rank0.pt'), weights_only=True)
         r1 = torch.load(os.path.join(d, 'rank1.pt'), weights_only=True)
     whole = _train(0, 1, None)
@@ -92,7 +96,7 @@ def test_two_ranks_match_whole_batch_training():
         a = r0[1][n]
         assert (a is None) == (g is None), n
         if g is not None:
-            tol = 4e-3 * float(g.abs().max()) + 1e-7
+            tol = (4e-3 if big[0] == 'fp32' or 'classifier.3' not in n else 1.2e-2) * float(g.abs().max()) + 1e-7
             assert float((a - g).abs().max()) <= tol, (n, float((a - g).abs().max()), tol)
     assert any(g is None for g in whole[1].values())
     # the trajectory stays together (bf16 arithmetic, different tile grouping per batch split)

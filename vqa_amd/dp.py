@@ -21,6 +21,9 @@ all-reduce:
 The wrapper works on any backend torch.distributed offers (tests run it on gloo/CPU with a
 stand-in module); on MI355X the backend is "nccl", i.e. RCCL over xGMI.
 """
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -42,9 +45,23 @@ def loss_weight(n, rank, world):
 
 
 class DataParallelExecutor:
-    def __init__(self, net, process_group=None, direct_bytes=32 << 20):
+    def __init__(self, net, process_group=None, direct_bytes=32 << 20, big_transport='fp32', big_algo='all_reduce'):
+        """big_transport / big_algo apply to gradients of at least `direct_bytes` (the first linear
+        layer's 411 MB weight gradient, 87 % of all gradient bytes):
+          big_transport 'fp32' (default: N ranks give the gradients of one rank on the whole batch to
+              fp32 rounding) or 'bf16' (the gradient crosses the links as bf16 - half the wire time,
+              within the 2e-2 gradient tolerance of the bf16 path, no longer bit-near to one rank);
+          big_algo 'all_reduce' (default) or 'reduce_scatter': an explicit reduce-scatter into this
+              rank's 1/N slice followed by an all-gather, the two halves of a ring all-reduce as
+              separate collectives (on the xGMI mesh each moves (N-1)/N of the bytes over all links
+              at once; the split is also where a sharded optimizer step would go)."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
+        if big_transport not in ('fp32', 'bf16') or big_algo not in ('all_reduce', 'reduce_scatter'):
+            raise ValueError('big_transport must be fp32 or bf16, big_algo all_reduce or reduce_scatter')
+        self.big_transport, self.big_algo = big_transport, big_algo
+        self._big_bufs = {}          # name -> persistent (bf16 staging, shard) buffers
+        self._big_after = []         # (fp32 gradient, bf16 staging) to cast back once the collectives are done
         self.net = net
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
@@ -81,7 +98,9 @@ class DataParallelExecutor:
         return self.forward(x, program)
 
     def forward(self, x, program):
-        self._presence_launched = False
+        # (_presence_launched belongs to the pending backward: an eval / no_grad forward between a
+        # training forward and finish_grad_sync() - the MAPO scoring pattern, Train_model.py:339-369 -
+        # leaves it alone; finish_grad_sync() clears it)
         out = self.net(x, program)
         counts = getattr(self.net, 'last_token_counts', None)
         if counts is not None and torch.is_grad_enabled() and not self._presence_launched:
@@ -113,14 +132,46 @@ class DataParallelExecutor:
 
     # ---------------------------------------------------------------- backward hooks
     def _reduce(self, t):
+        if os.environ.get('VQA_DP_DEBUG'):
+            print('[dp rank %d] issue collective %d: %d elements on stream %x' % (
+                self.rank, len(self._works), t.numel(), torch.cuda.current_stream().cuda_stream if t.is_cuda else 0),
+                file=sys.stderr, flush=True)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._works.append(dist.all_reduce(t, op=op, group=self.pg, async_op=True))
+
+    def _reduce_big(self, name, grad):
+        """The collective(s) for one large gradient, issued on the current stream: optionally through
+        a bf16 copy, optionally as reduce-scatter + all-gather.  The result is in `grad` (fp32) once
+        finish_grad_sync() has run."""
+        if self.big_transport == 'fp32' and self.big_algo == 'all_reduce':
+            return self._reduce(grad)
+        flat = grad.view(-1)
+        n = flat.numel()
+        bufs = self._big_bufs.get(name)
+        if bufs is None or bufs[0] != (n, grad.device):
+            stage = torch.empty(n, dtype=torch.bfloat16, device=grad.device) if self.big_transport == 'bf16' else None
+            shard = (torch.empty(n // self.world, dtype=torch.bfloat16 if stage is not None else torch.float32, device=grad.device)
+                     if self.big_algo == 'reduce_scatter' and n % self.world == 0 else None)
+            bufs = self._big_bufs[name] = ((n, grad.device), stage, shard)
+        _, stage, shard = bufs
+        src = flat
+        if stage is not None:
+            stage.copy_(flat)                # fp32 -> bf16 on the current stream
+            src = stage
+            self._big_after.append((flat, stage))
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if shard is None:
+            self._works.append(dist.all_reduce(src, op=op, group=self.pg, async_op=True))
+            return
+        w = dist.reduce_scatter_tensor(shard, src, op=op, group=self.pg, async_op=True)
+        w.wait()       # RCCL: the current stream waits, the host does not; the all-gather reads the slice
+        self._works.append(dist.all_gather_into_tensor(src, shard, group=self.pg, async_op=True))
 
     def _on_grad(self, name, grad):
         self._pending = True
         if grad.numel() * grad.element_size() >= self.direct_bytes and grad.is_contiguous():
             self._direct[name] = grad
-            self._reduce(grad)               # in place, overlapped with the rest of backward
+            self._reduce_big(name, grad)     # in place, overlapped with the rest of backward
         else:
             self._small[name] = grad
 
@@ -169,9 +220,17 @@ class DataParallelExecutor:
         """Wait for the collectives and install the averaged gradients on the parameters."""
         if not self._pending:
             return
-        for w in self._works:
+        dbg = os.environ.get('VQA_DP_DEBUG')
+        for i, w in enumerate(self._works):
+            if dbg:
+                print('[dp rank %d] waiting for collective %d of %d' % (self.rank, i, len(self._works)), file=sys.stderr, flush=True)
             w.wait()
+        if dbg:
+            print('[dp rank %d] all collectives done' % self.rank, file=sys.stderr, flush=True)
         self._works = []
+        for flat, stage in self._big_after:
+            flat.copy_(stage)                # bf16 -> fp32, behind the waits above on this stream
+        self._big_after = []
         present = None
         if self._presence_launched:
             self._presence_event.synchronize()
@@ -222,6 +281,7 @@ class DataParallelExecutor:
             p.grad = self._flat[off:off + cnt].view(p.shape)
         self._direct, self._small, self._presence, self._pending = {}, {}, None, False
         self._groups, self._small_groups = [], []
+        self._presence_launched = False
 
     # convenience passthroughs
     def parameters(self):
