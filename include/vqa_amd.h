@@ -319,6 +319,12 @@ typedef struct {
 
 int vqa_gemm(const vqa_gemm_params* p, void* stream);
 
+/* The same product at fp32 (operands, accumulation on v_mfma_f32_16x16x4_f32, result) for the linear
+ * layers of the tolerance configuration (Module_Model.py:85-92 and their gradients): out_mode must
+ * be 1; no padding or alignment requirements; `mask`, when set, is fp32 with C's geometry (result
+ * times (mask > 0), unsplit only); split_k > 1 writes slabs as vqa_gemm does. */
+int vqa_gemm_f32(const vqa_gemm_params* p, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Layout and elementwise helpers
  * ------------------------------------------------------------------------------------------ */
@@ -338,6 +344,12 @@ int vqa_fc_grad_from_nhwc(const float* g, float* out, int32_t F, int32_t P, void
  * flatten order of Layers.py:42-44, so that the weight gradient of the linear layer behind it
  * (Module_Model.py:86-88) comes out of its GEMM in the reference's own layout.  C % 64 == 0. */
 int vqa_transpose_hw_c(const void* x, void* out, int32_t N, int32_t C, void* stream);
+/* Batched fp32 transposition out[i][c][r] = x[i][r][c] for i < n, r < rows, c < cols; x is dense
+ * [n][rows][cols], rows of out are ld_out floats apart and its matrices out_stride apart (the rest
+ * of out is left alone).  The fp32 path's layout changes: the loader's NCHW batch (Train_model.py:311)
+ * -> channels-last maps, and channels-last <-> the flatten order of Layers.py:42-44. */
+int vqa_transpose_f32(const float* x, float* out, int32_t n, int32_t rows, int32_t cols, int64_t ld_out,
+                      int64_t out_stride, void* stream);
 /* out[rows][ld_out] = act(sum over `slabs` split-K slabs of acc fp32 [rows][ld_acc] + bias[col]) for
  * col < cols; out is bf16, or fp32 when out_f32 */
 int vqa_bias_act(const float* acc, const float* bias, void* out, int32_t rows, int32_t cols,

@@ -468,3 +468,41 @@ def test_slot_sum_mask():
     got = arena[S + 2:].to(torch.float32).cpu()
     close(got[0], (x[0] + x[3]) * (mk[0] > 0))
     close(got[1], (x[1] + x[2] + x[4] + x[5]) * (mk[1] > 0))
+
+
+@pytest.mark.parametrize('M,N,K', [(37, 70, 50), (128, 64, 256), (5, 200, 1000)])
+def test_gemm_f32_all_layouts_ragged_sizes_split_and_mask(M, N, K):
+    """vqa_gemm_f32: exact fp32 products and sums (v_mfma_f32_16x16x4_f32) against float64 on the
+    same fp32 inputs, 1e-5; sizes that are multiples of nothing, the four operand layouts, split-k
+    slabs and the masked form."""
+    from vqa_amd import ops
+    a, b = rnd((M, K), 60), rnd((N, K), 61)
+    ref = (a.double() @ b.double().t()).float()
+    ad, bd = a.to(dev()), b.to(dev())
+    at, bt = ad.t().contiguous(), bd.t().contiguous()
+    for akm, bkm in ((False, False), (False, True), (True, True), (True, False)):
+        c = torch.full((M, N), 7.0, device=dev())
+        ops.gemm_f32(at if akm else ad, bt if bkm else bd, c, M, N, K, lda=M if akm else K, ldb=N if bkm else K, ldc=N,
+                     a_kmajor=akm, b_kmajor=bkm)
+        torch.cuda.synchronize()
+        close(c.cpu(), ref, 1e-5)
+    c = torch.full((3, M, N), 7.0, device=dev())
+    ops.gemm_f32(ad, bd, c, M, N, K, lda=K, ldb=K, ldc=N, split_k=3)
+    torch.cuda.synchronize()
+    close(c.sum(0).cpu(), ref, 1e-5)
+    mk = F.relu(rnd((M, N), 62))
+    c = torch.full((M, N), 7.0, device=dev())
+    ops.gemm_f32(ad, bt, c, M, N, K, lda=K, ldb=N, ldc=N, b_kmajor=True, mask=mk.to(dev()))
+    torch.cuda.synchronize()
+    close(c.cpu(), ref * (mk > 0), 1e-5)
+
+
+def test_transpose_f32_batched_with_padded_rows():
+    from vqa_amd import ops
+    n, rows, cols, ld = 3, 50, 196, 64
+    x = rnd((n, rows, cols), 63)
+    out = torch.full((n, cols, ld), -1.0, device=dev())
+    ops.transpose_f32(x.to(dev()), out, n, rows, cols, ld_out=ld, out_stride=cols * ld)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :, :rows].cpu(), x.permute(0, 2, 1))
+    assert float(out[:, :, rows:].max()) == -1.0           # the padding is left alone

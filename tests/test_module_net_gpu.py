@@ -218,8 +218,8 @@ def test_errors_on_gpu_module(vocab):
 
 
 # ---------------------------------------------------------------------------------------------
-# fp32 path (net.precision = 'fp32'): fp32 storage, v_mfma_f32_16x16x4_f32 convolutions, rocBLAS fp32
-# linear layers.  Tolerance: 1e-3 relative L2 error on logits and on every gradient.
+# fp32 path (net.precision = 'fp32'): fp32 storage, v_mfma_f32_16x16x4_f32 convolutions and linear
+# layers.  Tolerance: 1e-3 relative L2 error on logits and on every gradient.
 # Logits are compared with the free-running fp32 oracle.  Gradients are compared twice: with the
 # oracle whose stored activations are forced to the HIP path's (the exact vector-Jacobian product at
 # the same ReLU masks) at 1e-3, and with the free-running oracle at 5e-2.  The second bound is looser

@@ -102,6 +102,8 @@ SIGNATURES = {
     'vqa_wgrad_tiles_noalloc': (i32, [C.POINTER(WgradParams), i32, i32, vp, i64, vp]),
     'vqa_unpack_conv_grad': (i32, [vp, vp, i32, i32, i32, i32, i64, vp]),
     'vqa_gemm': (i32, [C.POINTER(GemmParams), vp]),
+    'vqa_gemm_f32': (i32, [C.POINTER(GemmParams), vp]),
+    'vqa_transpose_f32': (i32, [vp, vp, i32, i32, i32, i64, i64, vp]),
     'vqa_nchw_to_nhwc': (i32, [vp, vp, i32, i32, i32, vp]),
     'vqa_nhwc_to_nchw': (i32, [vp, vp, i32, i32, vp]),
     'vqa_cast_pad': (i32, [vp, vp, i32, i32, i32, i32, vp]),

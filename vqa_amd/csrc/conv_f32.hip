@@ -265,3 +265,141 @@ extern "C" int vqa_slot_sum_mask_f32(float* arena, const int32_t* offsets, const
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_slot_sum_mask_f32: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMM for the linear layers of the tolerance configuration (nn.Linear of
+// Module_Model.py:85-92 and autograd's gradients of it): C[M][N] = A * B on
+// v_mfma_f32_16x16x4_f32, exact fp32 products and sums.  Same parameter block as vqa_gemm (operand
+// layouts a_kmajor / b_kmajor, split-k into fp32 slabs that vqa_bias_act adds), with fp32 operands,
+// no alignment or padding requirements (every access is guarded) and an fp32 mask (geometry of C,
+// unsplit only).  64 x 64 tile per workgroup, 4 waves of 32 x 32, K step 16 through LDS: plain
+// structure, built for the 1e-3 check and not for speed.
+// ---------------------------------------------------------------------------------------------
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(vqa_gemm_params p) {
+    __shared__ float As[64][17];
+    __shared__ float Bs[16][68];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1, l15 = lane & 15, lq = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, kz = blockIdx.z;
+    const int per = ((p.K + 15) / 16 + p.split_k - 1) / p.split_k * 16;
+    const int kbeg = kz * per, kend = min(p.K, kbeg + per);
+    const float* a = (const float*)p.a;
+    const float* b = (const float*)p.b;
+    f32x4v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        // each thread brings 4 elements of either tile, along whichever axis is contiguous in memory
+        if (!A_KM) {
+            const int m = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                As[m][kk + j] = (m0 + m < p.M && k0 + kk + j < kend) ? a[(int64_t)(m0 + m) * p.lda + k0 + kk + j] : 0.f;
+        } else {
+            const int kk = tid >> 4, m = (tid & 15) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                As[m + j][kk] = (m0 + m + j < p.M && k0 + kk < kend) ? a[(int64_t)(k0 + kk) * p.lda + m0 + m + j] : 0.f;
+        }
+        if (!B_KM) {
+            const int n = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                Bs[kk + j][n] = (n0 + n < p.N && k0 + kk + j < kend) ? b[(int64_t)(n0 + n) * p.ldb + k0 + kk + j] : 0.f;
+        } else {
+            const int kk = tid >> 4, n = (tid & 15) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                Bs[kk][n + j] = (n0 + n + j < p.N && k0 + kk < kend) ? b[(int64_t)(k0 + kk) * p.ldb + n0 + n + j] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+            float af[2], bf_[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                af[i] = As[wm * 32 + i * 16 + l15][k4 * 4 + lq];
+                bf_[i] = Bs[k4 * 4 + lq][wn * 32 + i * 16 + l15];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf_[ni], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // lane holds C[m = 4 * lq + r][n = l15] of each 16 x 16 block
+    float* c = (float*)p.c + (int64_t)kz * p.M * p.ldc;
+    const float* mk = (const float*)p.mask;
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + wm * 32 + mi * 16 + 4 * lq + r, n = n0 + wn * 32 + ni * 16 + l15;
+                if (m < p.M && n < p.N) {
+                    float v = acc[mi][ni][r];
+                    const int64_t o = (int64_t)m * p.ldc + n;
+                    if (mk) v = mk[o] > 0.f ? v : 0.f;
+                    c[o] = v;
+                }
+            }
+}
+
+extern "C" int vqa_gemm_f32(const vqa_gemm_params* p, void* stream) {
+    if (!p || !p->a || !p->b || !p->c || p->M <= 0 || p->N <= 0 || p->K <= 0 || p->split_k < 1 || p->out_mode != 1 ||
+        (p->mask && p->split_k != 1)) {
+        vqa_set_error("vqa_gemm_f32: bad argument (fp32 result only; a mask needs split_k == 1)");
+        return VQA_EINVAL;
+    }
+    dim3 grid((p->N + 63) / 64, (p->M + 63) / 64, p->split_k), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (!p->a_kmajor && !p->b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, *p);
+    else if (!p->a_kmajor && p->b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, *p);
+    else if (p->a_kmajor && p->b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, *p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, *p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_gemm_f32: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}
+
+// Batched fp32 transposition out[n][c][r] = x[n][r][c] (rows r < R, columns c < Cc), rows of `out`
+// ld_out floats apart and matrices out_stride apart: the flatten order of Layers.py:42-44 (c*196+hw)
+// <-> the channels-last maps of the fp32 path, and the loader's NCHW batch -> channels-last.
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int R,
+                                                            int Cc, int64_t ld_out, int64_t out_stride) {
+    __shared__ float t[32][33];
+    const int n = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* xs = x + (int64_t)n * R * Cc;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        t[ty + 8 * i][tx] = (r < R && c < Cc) ? xs[(int64_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    float* os = out + (int64_t)n * out_stride;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < Cc && r < R) os[(int64_t)c * ld_out + r] = t[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int vqa_transpose_f32(const float* x, float* out, int32_t n, int32_t rows, int32_t cols, int64_t ld_out,
+                                 int64_t out_stride, void* stream) {
+    if (!x || !out || n <= 0 || rows <= 0 || cols <= 0 || ld_out < rows || n > 65535) {
+        vqa_set_error("vqa_transpose_f32: bad argument");
+        return VQA_EINVAL;
+    }
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, n), dim3(256), 0, (hipStream_t)stream,
+                       x, out, rows, cols, ld_out, out_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_transpose_f32: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}

@@ -222,6 +222,8 @@ class ModuleNet(nn.Module):
         self._packed = {}
         self._pack_bufs = {}          # persistent destinations of the packed convolution weights
         self._pack_targets = None
+        self._param_epoch = 0         # see _params_changed
+        self._f32_cache = None        # (key, weight arrays of the fp32 path)
         self._conv_packs_fresh = False  # set by vqa_amd.optim.FusedAdam: it rewrote those copies with its update
         self._fc1_packed = None       # persistent bf16 copy of the first linear layer's weight
         self.segment_marks = None     # diagnostics: see _mark
@@ -234,7 +236,7 @@ class ModuleNet(nn.Module):
         # run nodes that have slack in later tree levels so that launches fill whole rounds of the device
         self.balance_levels = True
         # 'bf16': bf16 storage and MFMA operands, fp32 accumulation (the throughput path);
-        # 'fp32': fp32 storage and fp32 MFMA for every convolution, rocBLAS fp32 for the linear layers
+        # 'fp32': fp32 storage and fp32 MFMA for every convolution and linear layer
         # (the tolerance configuration: results within 1e-3 of the reference's fp32 arithmetic)
         self.precision = 'bf16'
         self.grad_ready_hook = None   # set by the data-parallel wrapper: called as (name, grad tensor)
@@ -716,10 +718,26 @@ class ModuleNet(nn.Module):
             self.last_state = st
         return st
 
+    def _params_changed(self):
+        """Parameters are about to change without their version counters moving (a backward pass is
+        followed by an optimizer step, and torch's fused optimizers and vqa_amd.optim.FusedAdam do not
+        bump versions): every cached copy derived from them is out of date."""
+        self._packed_stale = True
+        self._param_epoch += 1
+
     # ------------------------------------------------------------------ fp32 path
     def _weights_f32(self, dev):
         """Plain fp32 [group][tap][k][n] weight arrays for the fp32 kernels, forward and
         input-gradient (flipped taps, transposed) forms."""
+        plist = self._param_groups()
+        key = (tuple(p.data_ptr() for _, p in plist), tuple(p._version for _, p in plist), self._param_epoch, str(dev))
+        if self._f32_cache is not None and self._f32_cache[0] == key:
+            return self._f32_cache[1]
+        pk = self._build_weights_f32(dev)
+        self._f32_cache = (key, pk)
+        return pk
+
+    def _build_weights_f32(self, dev):
         d = self._dims
         c, p_, cin, cpad = d['c'], d['p'], d['cin'], d['cin_pad']
         nv = len(self._tokens)
@@ -756,48 +774,67 @@ class ModuleNet(nn.Module):
         d = self._dims
         dev = x.device
         N, c, p_, cin, cpad = x.size(0), d['c'], d['p'], d['cin'], d['cin_pad']
+        f32t = torch.float32
         plan = Plan(program.detach().cpu().numpy(), self.vocab, c, self.wgrad_chunk, _lib.PLAN_SKIP_FUSED)
         info = plan.info
         self.used_fns = torch.from_numpy(plan.used_fns()).to(program.device)
         self.last_token_counts = plan.token_counts()
         if self.plan_ready_hook is not None:
             self.plan_ready_hook(self.last_token_counts, dev, need_grad)
-        st = _CallState(N=N, plan=plan, f32=True, x_dtype=x.dtype)
-        st['pk'] = pk = self._weights_f32(dev)
-        st['blob'] = blob = torch.from_numpy(plan.blob()).to(dev)
-        slots = info.slots_total if need_grad else info.slots_fwd
-        st['arena'] = arena = torch.empty(slots * HW * c, dtype=torch.float32, device=dev)
-        xn = torch.zeros(N, HW, cpad, dtype=torch.float32, device=dev)
-        xn[:, :, :cin] = x.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(N, HW, cin)
-        st['x_nhwc'] = xn
-        slot = (HW * c, c)
-        self._conv(st, xn, arena, pk['w_stem0'], 'STEM0_TILES', 9, cpad // 128, c, (HW * cpad, cpad), slot,
-                   bias=pk['b_stem0'], relu=True, f32=True)
-        self._conv(st, arena, arena, pk['w_stem1'], 'STEM1_TILES', 9, c // 128, c, slot, slot,
-                   bias=pk['b_stem1'], relu=True, f32=True)
-        tctx = self._tree_ctx(st, pk)
-        tctx.flags = _lib.TREE_F32
-        _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
-        st['c1'] = c1 = torch.empty(N, HW * p_, dtype=torch.float32, device=dev)
-        self._conv(st, arena, c1, pk['w_cls'], 'CLS_FWD_TILES', 1, c // 128, p_, slot, (HW * p_, p_),
-                   bias=pk['b_cls'], relu=True, f32=True)
-        # linear layers on rocBLAS fp32; the first one's weight re-ordered from the reference's
-        # flatten order c*196+hw (Layers.py:42-44) to the channels-last hw*P+c
-        acts, ws_ = [c1], []
-        fcs = list(d['fcs']) + [d['na']]
-        with torch.no_grad():
+        ws = self._pool.acquire()
+        st = _CallState(N=N, plan=plan, f32=True, x_dtype=x.dtype, ws=ws)
+        try:
+            st['pk'] = pk = self._weights_f32(dev)
+            blob_host = torch.from_numpy(plan.blob())
+            st['blob'] = blob = ws.get('blob32', blob_host.numel(), torch.int32, dev)
+            blob.copy_(blob_host)
+            slots = info.slots_total if need_grad else info.slots_fwd
+            st['arena'] = arena = ws.get('arena32', slots * HW * c, f32t, dev)
+            # the loader's NCHW batch (Train_model.py:311) -> channels-last fp32 [N][196][cin_pad]
+            xn = ws.bufs.get('x32')
+            if xn is None or xn.numel() != N * HW * cpad or xn.device != dev:
+                xn = ws.bufs['x32'] = torch.zeros(N * HW * cpad, dtype=f32t, device=dev)   # padding channels stay zero
+            ops.transpose_f32(x.detach().to(f32t).contiguous(), xn, N, cin, HW, ld_out=cpad, out_stride=HW * cpad)
+            st['x_nhwc'] = xn
+            slot = (HW * c, c)
+            self._conv(st, xn, arena, pk['w_stem0'], 'STEM0_TILES', 9, cpad // 128, c, (HW * cpad, cpad), slot,
+                       bias=pk['b_stem0'], relu=True, f32=True)
+            self._conv(st, arena, arena, pk['w_stem1'], 'STEM1_TILES', 9, c // 128, c, slot, slot,
+                       bias=pk['b_stem1'], relu=True, f32=True)
+            tctx = self._tree_ctx(st, pk)
+            tctx.flags = _lib.TREE_F32
+            _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
+            st['c1'] = c1 = ws.get('c1_32', N * HW * p_, f32t, dev)
+            self._conv(st, arena, c1, pk['w_cls'], 'CLS_FWD_TILES', 1, c // 128, p_, slot, (HW * p_, p_),
+                       bias=pk['b_cls'], relu=True, f32=True)
+            # Flatten (Layers.py:42-44) orders a map c*196+hw: the channels-last map is transposed per
+            # sample, so the linear layers use the reference's weights as they are and their weight
+            # gradients come out in the reference's layout
+            flat = ws.get('flat32', N * HW * p_, f32t, dev)
+            ops.transpose_f32(c1, flat, N, HW, p_)
+            # linear layers (Module_Model.py:85-92) on fp32 MFMA: split-k slabs, then bias (+ ReLU)
+            acts = [flat]
+            prev_dim = HW * p_
+            fcs = list(d['fcs']) + [d['na']]
             for li, fo in enumerate(fcs):
                 lin = self.classifier[self._fc_idx[li]]
-                w = lin.weight.detach()
-                if li == 0:
-                    w = w.view(fo, p_, HW).permute(0, 2, 1).reshape(fo, HW * p_).contiguous()
-                ws_.append(w)
-                y = torch.addmm(lin.bias.detach(), acts[-1], w.t())
-                if li < len(fcs) - 1:
-                    y = torch.relu_(y)
-                acts.append(y)
-        st['acts'], st['fc_w'] = acts[:-1], ws_
-        st['logits'] = acts[-1]
+                tiles = -(-N // 64) * -(-fo // 64)
+                split = max(1, min(prev_dim // 256, -(-1024 // tiles)))
+                acc = ws.get('fc32_acc%d' % li, split * N * fo, f32t, dev)
+                ops.gemm_f32(acts[-1], lin.weight.detach(), acc, N, fo, prev_dim, lda=prev_dim, ldb=prev_dim, ldc=fo,
+                             split_k=split)
+                last = li == len(fcs) - 1
+                out = torch.empty(N, fo, dtype=f32t, device=dev) if last else ws.get('fc32_act%d' % li, N * fo, f32t, dev)
+                ops.bias_act(acc, lin.bias.detach(), out, N, fo, fo, fo, not last, slabs=split, slab_stride=N * fo)
+                if last:
+                    st['logits'] = out
+                else:
+                    acts.append(out)
+                    prev_dim = fo
+            st['acts'] = acts
+        except BaseException:
+            st.release()
+            raise
         if self.keep_state:
             self.last_state = st
         return st
@@ -808,20 +845,32 @@ class ModuleNet(nn.Module):
         dev = dlogits.device
         lib = _lib.load()
         c, p_, cin, cpad, nv = d['c'], d['p'], d['cin'], d['cin_pad'], len(self._tokens)
-        arena, blob, acts, fc_w = st['arena'], st['blob'], st['acts'], st['fc_w']
+        arena, blob, acts = st['arena'], st['blob'], st['acts']
         slot = (HW * c, c)
         fcs = list(d['fcs']) + [d['na']]
         f32 = dict(dtype=torch.float32, device=dev)
         grads = {}
+        ws = st['ws']
+        dims_in = [HW * p_] + list(d['fcs'])
         g = dlogits.detach().to(torch.float32).contiguous()
+        g_ld = fcs[-1]
         for li in range(len(fcs) - 1, -1, -1):
             name = 'classifier.%d' % self._fc_idx[li]
-            gw = g.t() @ acts[li]
-            if li == 0:
-                gw = gw.view(fcs[0], HW, p_).permute(0, 2, 1).reshape(fcs[0], p_ * HW).contiguous()
-            grads[name + '.weight'], grads[name + '.bias'] = gw, g.sum(0)
-            g = (g @ fc_w[li]) * (acts[li] > 0)
-        dc1 = g.contiguous()      # [N][196][P], already times (C1 > 0)
+            fo, fi = fcs[li], dims_in[li]
+            lin = self.classifier[self._fc_idx[li]]
+            # dW[fo][fi] = g^T x input activations (both stored sample-major: k-major operands), in the
+            # reference's own layout since the first layer's input is the map in Flatten's order
+            gw = torch.empty(fo, fi, **f32)
+            ops.gemm_f32(g, acts[li], gw, fo, fi, N, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
+            gb = torch.zeros(fo, **f32)
+            ops.col_sum(g, gb, N, fo, g_ld)
+            grads[name + '.weight'], grads[name + '.bias'] = gw, gb
+            # input gradient, times (input > 0): the input came out of a ReLU
+            gin = ws.get('fc32_gin%d' % li, N * fi, torch.float32, dev)
+            ops.gemm_f32(g, lin.weight.detach(), gin, N, fi, fo, lda=g_ld, ldb=fi, ldc=fi, b_kmajor=True, mask=acts[li])
+            g, g_ld = gin, fi
+        dc1 = ws.get('dc1_32', N * HW * p_, torch.float32, dev)      # back to channels-last [N][196][P]
+        ops.transpose_f32(g, dc1, N, p_, HW)
 
         it_off, it_cnt = plan.section('SAMPLE_ITEMS')
         sec = lambda n: (blob, plan.section(n)[0])
@@ -885,7 +934,7 @@ class ModuleNet(nn.Module):
                 if self.grad_ready_hook is not None:
                     self.grad_ready_hook(name, gr)
             out.append(gr if p.requires_grad else None)
-        self._packed_stale = True
+        self._params_changed()
         if self.backward_done_hook is not None:
             self.backward_done_hook()
         if not self.keep_state:
@@ -1109,7 +1158,7 @@ class ModuleNet(nn.Module):
             out.append(gr if p.requires_grad else None)
         torch.cuda.current_stream(dev).wait_event(side_done)
         self._mark('bwd_end')
-        self._packed_stale = True
+        self._params_changed()
         if self.backward_done_hook is not None:
             self.backward_done_hook()
         if not self.keep_state:

@@ -142,6 +142,27 @@ def gemm(a, b, c, M, N, K, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, out
     _lib.check(_lib.load().vqa_gemm(C.byref(p), _stream()))
 
 
+def gemm_f32(a, b, c, M, N, K, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, split_k=1, mask=None):
+    """fp32 operands and result on fp32 MFMA (vqa_gemm_f32); layouts as gemm()."""
+    _need_cuda(a, b, c)
+    assert a.dtype == b.dtype == c.dtype == torch.float32 and (mask is None or mask.dtype == torch.float32)
+    p = _lib.GemmParams()
+    p.a, p.b, p.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    p.mask = mask.data_ptr() if mask is not None else 0
+    p.lda, p.ldb, p.ldc, p.M, p.N, p.K = lda, ldb, ldc, M, N, K
+    p.a_kmajor, p.b_kmajor, p.out_mode, p.split_k = int(a_kmajor), int(b_kmajor), 1, split_k
+    _lib.check(_lib.load().vqa_gemm_f32(C.byref(p), _stream()))
+
+
+def transpose_f32(x, out, n, rows, cols, ld_out=None, out_stride=None):
+    """out[i][c][r] = x[i][r][c], fp32; rows of out ld_out apart (default rows), matrices out_stride apart."""
+    _need_cuda(x, out)
+    assert x.dtype == out.dtype == torch.float32
+    ld_out = rows if ld_out is None else ld_out
+    out_stride = cols * ld_out if out_stride is None else out_stride
+    _lib.check(_lib.load().vqa_transpose_f32(_ptr(x), _ptr(out), n, rows, cols, ld_out, out_stride, _stream()))
+
+
 def nchw_to_nhwc(x, out, n, cin, cpad):
     _need_cuda(x, out)
     _lib.check(_lib.load().vqa_nchw_to_nhwc(_ptr(x), _ptr(out), n, cin, cpad, _stream()))
