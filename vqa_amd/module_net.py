@@ -214,6 +214,8 @@ class ModuleNet(nn.Module):
         self._fc_idx = [i for i, m in enumerate(self.classifier) if isinstance(m, nn.Linear)]
         self._pool = _WorkspacePool()
         self._side = None              # stream for host<->device traffic that must not queue behind compute
+        self._lay = None               # stream of the input layout pass (see _run_forward)
+        self.stem_pieces = int(os.environ.get('VQA_STEM_PIECES', '2'))
         self._stem_tile_cache = {}
         self._packed_key = None
         self._packed_stale = False
@@ -515,13 +517,12 @@ class ModuleNet(nn.Module):
         if isinstance(x, FeatureRows):
             if cin != cpad or x.table.size(2) != cin or x.table.dtype != torch.bfloat16 or not x.table.is_contiguous():
                 raise ValueError('feature table must be contiguous bf16 [R, 196, %d]' % cpad)
-            return x.table, x.index
+            return x.table, x.index, None
         if (x.dtype == torch.bfloat16 and cin == cpad and x.stride() == (HW * cin, 1, 14 * cin, cin)):
-            return x.detach(), None
+            return x.detach(), None, None
         xs = x.detach().to(torch.float32).contiguous()
         xn = ws.get('x_nhwc', M * HW * cpad, torch.bfloat16, dev)
-        ops.nchw_to_nhwc(xs, xn, M, cin, cpad)
-        return xn, None
+        return xn, None, xs           # the layout pass is the caller's: it pipelines it with the first convolution
 
     def _stem_tiles(self, N, dev):
         """Tile lists of the two stem convolutions (image i -> S0 slot N+i -> F slot i) and, behind
@@ -597,7 +598,7 @@ class ModuleNet(nn.Module):
             slot = (HW * c, c)
             stem_elems = 4 * M * HW * c      # stem maps S0, F and the scene module's H, Y per image
             arena_full = ws.get_capacity('arena', stem_elems, torch.bfloat16, dev)
-            xn, rows = self._stem_input(x, ws, M, dev)
+            xn, rows, xs = self._stem_input(x, ws, M, dev)
             st['x_nhwc'], st['x_rows'] = xn, rows
             stem_tiles = self._stem_tiles(M, dev)
             tiles0 = stem_tiles
@@ -606,8 +607,39 @@ class ModuleNet(nn.Module):
                 tiles0.copy_(stem_tiles[:8 * M])
                 tiles0.view(M, 8)[:, 0] = rows
             geo = dict(taps=9, n_out=c, dst_slot_stride=slot[0], dst_pix_stride=slot[1], w_group_stride=0, relu=True)
-            ops.conv_tiles(xn, arena_full, pk['w_stem0'], tiles0, M, k_chunks=cpad // 128,
-                           src_slot_stride=HW * cpad, src_pix_stride=cpad, bias=pk['b_stem0'], **geo)
+
+            def conv0(lo, hi):
+                ops.conv_tiles(xn, arena_full, pk['w_stem0'], tiles0, hi - lo, k_chunks=cpad // 128,
+                               src_slot_stride=HW * cpad, src_pix_stride=cpad, bias=pk['b_stem0'],
+                               tiles_offset=8 * lo, **geo)
+            if xs is None:
+                conv0(0, M)
+            else:
+                # fp32 NCHW -> bf16 channels-last is HBM-bound, the convolution behind it MFMA-bound:
+                # the batch goes through in pieces, the layout pass of piece k + 1 on a stream of its
+                # own under the convolution of piece k
+                cin = d['cin']
+                pieces = self.stem_pieces if M >= 64 * self.stem_pieces else 1
+                cuts = [M * k // pieces for k in range(pieces + 1)]
+                xn2 = xn.view(M, HW * cpad)
+                if pieces > 1 and (self._lay is None or self._lay.device != dev):
+                    self._lay = torch.cuda.Stream(dev)
+                ops.nchw_to_nhwc(xs[:cuts[1]], xn2[:cuts[1]], cuts[1], cin, cpad)
+                for k in range(pieces):
+                    if k + 1 < pieces:
+                        go = torch.cuda.Event()
+                        go.record(cur)                 # the layout of piece k is done: the next one may start
+                        with torch.cuda.stream(self._lay):
+                            self._lay.wait_event(go)
+                            ops.nchw_to_nhwc(xs[cuts[k + 1]:cuts[k + 2]], xn2[cuts[k + 1]:cuts[k + 2]],
+                                             cuts[k + 2] - cuts[k + 1], cin, cpad)
+                            laid = torch.cuda.Event()
+                            laid.record(self._lay)
+                    conv0(cuts[k], cuts[k + 1])
+                    if k + 1 < pieces:
+                        cur.wait_event(laid)
+                if pieces > 1:
+                    xs.record_stream(self._lay)
             ops.conv_tiles(arena_full, arena_full, pk['w_stem1'], stem_tiles, M, k_chunks=c // 128,
                            src_slot_stride=slot[0], src_pix_stride=slot[1], bias=pk['b_stem1'],
                            tiles_offset=8 * M, **geo)
