@@ -33,10 +33,14 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=1024, help='programs per GPU')
-    ap.add_argument('--module-dim', type=int, default=128)
-    ap.add_argument('--max-len', type=int, default=30)
-    ap.add_argument('--max-nodes', type=int, default=27)
+    ap.add_argument('--config', type=int, choices=[3, 5], default=3,
+                    help="BASELINE.json configuration: 3 = the headline (default model, batch 1024/GPU, programs of <= 27 nodes); "
+                         "5 = the deep-program stress (module width 256, programs of up to 60 nodes in 64 columns, batch 512/GPU); "
+                         "sets the defaults of --batch, --module-dim, --max-len and --max-nodes")
+    ap.add_argument('--batch', type=int, default=None, help='programs per GPU')
+    ap.add_argument('--module-dim', type=int, default=None)
+    ap.add_argument('--max-len', type=int, default=None)
+    ap.add_argument('--max-nodes', type=int, default=None)
     ap.add_argument('--batches', type=int, default=4, help='distinct resident synthetic batches cycled through')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of vqa_amd.optim.FusedAdam")
@@ -51,7 +55,13 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=64, help='batch of the CPU baseline (BASELINE config 1: 64)')
     ap.add_argument('--cpu-reps', type=int, default=3, help='timed repetitions of the CPU baseline')
-    return ap.parse_args()
+    a = ap.parse_args()
+    preset = {3: dict(batch=1024, module_dim=128, max_len=30, max_nodes=27),
+              5: dict(batch=512, module_dim=256, max_len=64, max_nodes=60)}[a.config]
+    for k, v in preset.items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    return a
 
 
 def cpu_baseline(vocab, batch, reps):

@@ -313,6 +313,43 @@ def test_gradient_with_respect_to_the_features(vocab, precision):
     assert torch.equal(x2.grad, xg.grad)
 
 
+def test_width_256_deep_programs_default_stem_and_classifier(vocab):
+    """BASELINE's deep-program stress at a size the oracle finishes in seconds: module width 256 (the
+    per-pass kernels: two 128-channel chunks per map), 1024-channel features, the default 512-channel
+    classifier projection, programs of up to 60 nodes in 64 columns.  Logits against the fp32 oracle,
+    gradients against the bf16-storage oracle at the HIP path's activations, 2e-2."""
+    from vqa_amd.module_net import ModuleNet
+    dims = dict(feature_dim=(1024, 14, 14), module_dim=256, classifier_proj_dim=512, classifier_fc_layers=(256,))
+    n = 12
+    prog = synth.synth_programs(5000, n, vocab, max_len=64, max_nodes=60)
+    assert (prog != 0).sum(1).max() >= 45
+    x = torch.from_numpy(synth.synth_features(5000, n, dims['feature_dim']))
+    ans = torch.from_numpy(synth.synth_answers(5000, n))
+    pt = torch.from_numpy(prog)
+    sd = synth.synth_state_dict(19, vocab, **dims)
+    with torch.no_grad():
+        l32 = ModuleNetRef(vocab, sd)(x, pt)
+    up = _ce_grad(l32, ans)
+    net = ModuleNet(False, vocab, **dims)
+    net.load_state_dict(sd)
+    net.cuda().train()
+    net.keep_state = True
+    logits = net(x.cuda(), pt.cuda())
+    logits.backward(up.cuda())
+    torch.cuda.synchronize()
+    assert rel(logits, l32) <= TOL, rel(logits, l32)
+    st = net.last_state
+    ref = ModuleNetRef(vocab, sd, storage='bf16', forced=lambda kind, i=0: net.stored_activation(st, kind, i))
+    ref(x, pt).backward(up)
+    assert torch.equal(net.used_fns.cpu(), ref.used_fns)
+    for k, p in net.named_parameters():
+        g = ref.grads()[k]
+        if g is None:
+            assert p.grad is None, k
+        else:
+            assert rel(p.grad, g) <= TOL, '%s %g' % (k, rel(p.grad, g))
+
+
 def test_second_backward_over_a_released_call_raises(vocab):
     from vqa_amd.module_net import ModuleNet
     dims = dict(feature_dim=(128, 14, 14), module_dim=128, classifier_proj_dim=128, classifier_fc_layers=(128,))
