@@ -77,3 +77,32 @@ def test_reference_checkpoint_round_trip(vocab, tmp_path):
     for k in state:
         assert torch.equal(out[k], state[k]), k
     net.share_memory()                      # Train_model.py:224
+
+
+def test_list_programs_become_the_prefix_rows_the_interpreter_runs():
+    """Opt-in list-of-dicts programs (the format Module_Model_tmp.py:142-167 executes): converted rows,
+    parsed by the oracle's interpreter, must run the same modules on the same inputs as the list says."""
+    import pytest
+    from oracle.module_net_ref import parse_row
+    from vqa_amd import vocab as V
+    vocab = V.make_vocab()
+    i2t = vocab['program_idx_to_token']
+
+    def fn(name, inputs, value=None):
+        return {'function': name, 'value_inputs': [value] if value else [], 'inputs': inputs}
+    prog = [fn('scene', []), fn('filter_color', [0], 'red'), fn('scene', []), fn('filter_shape', [2], 'cube'),
+            fn('unique', [3]), fn('unreached', [0]), fn('union', [1, 4]), fn('count', [6])]
+    chain = [fn('scene', []), fn('filter_size', [0], 'large'), fn('exist', [1])]
+    rows = V.lists_to_prefix_rows([prog, chain], vocab)
+    assert rows.shape == (2, 7) and rows.dtype.kind == 'i'       # the unreached entry is dropped
+    toks = [i2t[int(t)] for t in rows[0]]
+    assert toks == ['count', 'union', 'filter_color[red]', 'scene', 'unique', 'filter_shape[cube]', 'scene']
+    nodes, used = parse_row(rows[0].tolist(), i2t)
+    # execution order (post-order) and wiring: union gets filter_color[red](scene) and unique(filter_shape[cube](scene))
+    assert [n[0] for n in nodes] == ['scene', 'filter_color[red]', 'scene', 'filter_shape[cube]', 'unique', 'union', 'count']
+    assert nodes[5][2] == (1, 4) and nodes[6][2] == (5,) and used == [1] * 7
+    assert [i2t[int(t)] for t in rows[1]][:4] == ['exist', 'filter_size[large]', 'scene', '<NULL>']
+    with pytest.raises(KeyError):
+        V.lists_to_prefix_rows([[fn('scene', []), fn('no_such_function', [0])]], vocab)
+    with pytest.raises(TypeError):
+        V.lists_to_prefix_rows([[fn('scene', []), fn('union', [0])]], vocab)

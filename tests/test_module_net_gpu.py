@@ -479,3 +479,31 @@ def test_boundary_accepts_what_the_reference_accepts(vocab):
             replica(x, prog)
         with pytest.raises(AssertionError):
             net(x, prog[:3])
+
+
+def test_list_programs_raise_like_the_reference_unless_opted_in(vocab):
+    """The reference's list-of-dicts path dies on a missing attribute (Module_Model.py:186 reads
+    self.function_modules, which :136,149 leave commented out): AttributeError here too.  With
+    accept_program_lists the lists run as what that path was meant to do (Module_Model_tmp.py:142-167)
+    and give the logits of the equivalent prefix rows."""
+    from vqa_amd import vocab as V
+    from vqa_amd.module_net import ModuleNet
+    dims = small_dims(128)
+    net = ModuleNet(False, vocab, **dims)
+    net.load_state_dict(synth.synth_state_dict(3, vocab, **dims))
+    net.cuda().eval()
+
+    def fn(name, inputs, value=None):
+        return {'function': name, 'value_inputs': [value] if value else [], 'inputs': inputs}
+    progs = [[fn('scene', []), fn('filter_color', [0], 'red'), fn('scene', []), fn('unique', [2]), fn('union', [1, 3]), fn('count', [4])],
+             [fn('scene', []), fn('filter_size', [0], 'large'), fn('exist', [1])]]
+    x = torch.from_numpy(synth.synth_features(9, 2, dims['feature_dim'])).cuda()
+    with torch.no_grad():
+        with pytest.raises(AttributeError, match='function_modules'):
+            net(x, progs)
+        net.accept_program_lists = True
+        got = net(x, progs)
+        rows = torch.from_numpy(V.lists_to_prefix_rows(progs, vocab))
+        assert torch.equal(got, net(x, rows.cuda()))
+        ref = ModuleNetRef(vocab, synth.synth_state_dict(3, vocab, **dims))(x.cpu(), rows)
+    assert rel(got, ref) <= TOL

@@ -247,6 +247,8 @@ class ModuleNet(nn.Module):
         self.backward_done_hook = None
         self.last_token_counts = None
         self.keep_state = False       # tests: keep the last call's buffers in self.last_state
+        # list-of-dicts programs: False = the reference's behaviour (AttributeError); True = run them
+        self.accept_program_lists = False
         self.last_state = None
 
     # ------------------------------------------------------------------ parameters
@@ -422,8 +424,12 @@ class ModuleNet(nn.Module):
         if type(program) is list or type(program) is tuple:
             # the reference's list-of-dicts path reads self.function_modules, which its __init__
             # never sets (Module_Model.py:136,149,186): it raises AttributeError, and so do we
-            raise AttributeError("'ModuleNet' object has no attribute 'function_modules'")
-        elif type(program) is torch.Tensor and program.dim() == 2:
+            if not self.accept_program_lists:
+                raise AttributeError("'ModuleNet' object has no attribute 'function_modules'")
+            # opt-in: what that path was meant to do (Module_Model_tmp.py:142-167), through the same
+            # schedule as token rows
+            program = torch.from_numpy(V.lists_to_prefix_rows(program, self.vocab))
+        if type(program) is torch.Tensor and program.dim() == 2:
             pass
         else:
             raise ValueError('Unregonized program format')

@@ -72,3 +72,49 @@ def arity_table(vocab):
     i2t = vocab['program_idx_to_token']
     n = len(i2t)
     return [get_num_inputs(i2t[i]) for i in range(n)]
+
+
+def function_to_str(f):
+    """`{'function', 'value_inputs'}` -> token string; restates `Program_funcs.py:97-101`."""
+    value_str = ''
+    if f['value_inputs']:
+        value_str = '[%s]' % ','.join(f['value_inputs'])
+    return '%s%s' % (f['function'], value_str)
+
+
+def lists_to_prefix_rows(programs, vocab):
+    """List-of-dicts programs (one list per sample; entry j = {'function', 'value_inputs', 'inputs':
+    indices of earlier entries}; the last entry is the root - the format `forward_modules_json`
+    of `Module_Model_tmp.py:142-167` executes) as prefix token-id rows, `<NULL>`-padded, the form
+    the interpreter (`Module_Model.py:196-222`) runs: root first, then each input's subtree in
+    order.  An entry used by two parents is repeated (same values, computed twice); entries the root
+    does not reach contribute nothing to the output and are dropped.  A token outside the
+    vocabulary raises KeyError (the reference's dict lookup); an entry whose number of inputs is not
+    its module's arity raises TypeError (the reference's module call would)."""
+    import numpy as np
+    t2i = vocab['program_token_to_idx']
+    rows = []
+    for prog in programs:
+        if len(prog) == 0:
+            raise IndexError('list index out of range')       # module_outputs[-1] of nothing
+        out = []
+
+        def visit(j, depth=0):
+            f = prog[j]
+            tok = function_to_str(f)
+            idx = t2i[tok]
+            inputs = [] if tok == 'scene' else list(f['inputs'])
+            if len(inputs) != get_num_inputs(tok):
+                raise TypeError('%s takes %d inputs, %d given' % (tok, get_num_inputs(tok), len(inputs)))
+            if any(i >= j or i < 0 for i in inputs):
+                raise IndexError('list index out of range')   # inputs must be earlier entries
+            out.append(idx)
+            for i in inputs:
+                visit(i, depth + 1)
+        visit(len(prog) - 1)
+        rows.append(out)
+    T = max(len(r) for r in rows)
+    arr = np.zeros((len(rows), T), dtype=np.int64)
+    for i, r in enumerate(rows):
+        arr[i, :len(r)] = r
+    return arr
