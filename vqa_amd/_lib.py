@@ -58,7 +58,13 @@ class ResblockParams(C.Structure):
                 ('bias_first', vp), ('bias_second', vp), ('bias_pre', vp), ('tiles', vp),
                 ('slot_stride', i64), ('w_group_stride', i64), ('w_pre_group_stride', i64),
                 ('flags', i32), ('num_tiles', i32), ('num_pre', i32), ('num_post', i32),
-                ('phase_stamps', vp)]
+                ('phase_stamps', vp), ('level_info', vp)]
+
+
+class DevschedParams(C.Structure):
+    _fields_ = [(n, vp) for n in ('programs', 'arity', 'used', 'node', 'counts', 'hist', 'work', 'row_base',
+                                  'level_info', 'bin_off', 'bin_cursor', 'tiles', 'cls_tiles', 'error')] + \
+               [(n, i32) for n in ('N', 'T', 'V', 'null_id', 'start_id', 'scene_id')]
 
 
 SEC = {name: i for i, name in enumerate((
@@ -93,6 +99,7 @@ SIGNATURES = {
     'vqa_plan_slot': (i32, [vp, i32, i32]),
     'vqa_conv_tiles': (i32, [C.POINTER(ConvParams), i32, vp]),
     'vqa_resblock_tiles': (i32, [C.POINTER(ResblockParams), vp]),
+    'vqa_devsched_build': (i32, [C.POINTER(DevschedParams), vp]),
     'vqa_conv_tiles_f32': (i32, [C.POINTER(ConvParams), i32, vp]),
     'vqa_wgrad_tiles_f32': (i32, [C.POINTER(WgradParams), i32, vp]),
     'vqa_slot_sum_mask_f32': (i32, [vp, vp, vp, vp, vp, i32, i64, vp]),

@@ -356,7 +356,14 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     extern __shared__ __attribute__((aligned(16))) char halo[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const vqa_resblock_tile t = p.tiles[xcd_tile_index(blockIdx.x, p.num_tiles)];
+    // the tile: entry blockIdx.x of the list in XCD order, or, with the range in device memory
+    // (`level_info`: first tile, tiles), entry first + blockIdx.x if there is one
+    const vqa_resblock_tile* tp = p.tiles + xcd_tile_index(blockIdx.x, p.num_tiles);
+    if (p.level_info) {
+        if ((int)blockIdx.x >= p.level_info[1]) return;
+        tp = p.tiles + p.level_info[0] + blockIdx.x;
+    }
+    const vqa_resblock_tile t = *tp;
     // diagnostics: shader-clock timestamps of the phase boundaries of every tile
     unsigned long long* stamps = p.phase_stamps ? p.phase_stamps + (int64_t)blockIdx.x * 8 : nullptr;
 #define STAMP(i) if (stamps && tid == 0) stamps[i] = __builtin_readcyclecounter()

@@ -246,6 +246,14 @@ class ModuleNet(nn.Module):
         self.grad_group_hook = None   # likewise: (array [V, ...], {parameter name: row}) per kind of per-token parameter
         self.backward_done_hook = None
         self.last_token_counts = None
+        # programs that are in device memory (a sampler's output) are parsed and bucketed there, with
+        # no copy to the host, when no gradient is asked for (bf16, module width 128): same logits bit
+        # for bit as the host scheduler without balance_levels.  used_fns stays a device tensor, and a
+        # token id outside the vocabulary cannot raise from an asynchronous launch: it sets
+        # schedule_error (see raise_for_schedule_error)
+        self.schedule_on_device = False
+        self.schedule_error = None
+        self._arity_dev = None
         self.keep_state = False       # tests: keep the last call's buffers in self.last_state
         # list-of-dicts programs: False = the reference's behaviour (AttributeError); True = run them
         self.accept_program_lists = False
@@ -587,7 +595,13 @@ class ModuleNet(nn.Module):
             ready = torch.cuda.Event()
             ready.record(cur)
             side.wait_event(ready)
-            if program.is_cuda:
+            fused = c == 128 and self.fuse_residual_body
+            devs = (self.schedule_on_device and fused and not need_grad and image_index is None and
+                    program.is_cuda and program.device == dev)
+            if devs:
+                prog_dev = program.detach().to(torch.int64).contiguous()      # stays where it is
+                arrived = None
+            elif program.is_cuda:
                 prog_dev = program.detach().to(torch.int64).contiguous()
                 with torch.cuda.stream(side):
                     hprog.copy_(prog_dev, non_blocking=True)
@@ -649,62 +663,76 @@ class ModuleNet(nn.Module):
             ops.conv_tiles(arena_full, arena_full, pk['w_stem1'], stem_tiles, M, k_chunks=c // 128,
                            src_slot_stride=slot[0], src_pix_stride=slot[1], bias=pk['b_stem1'],
                            tiles_offset=8 * M, **geo)
-            fused = c == 128 and self.fuse_residual_body
             if fused:       # the scene level needs no plan either
                 ops.resblock_tiles(arena_full, pk['w_conv1'], pk['w_conv2'], stem_tiles, M,
                                    bias_first=pk['b_conv1'], bias_second=pk['b_conv2'], relu=True,
                                    tiles_offset=16 * M)
 
             self._mark('scene')
-            # programs -> plan -> tile lists on the device
-            if arrived is not None:
-                arrived.synchronize()
-            plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk,
-                        (_lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED) |
-                        (_lib.PLAN_BALANCE if self.balance_levels else 0) | _lib.PLAN_DEFER_BACKWARD,
-                        image_index=image_index, num_images=M if image_index is not None else None)
-            st['plan'] = plan
-            info = plan.info
-            self.last_token_counts = plan.token_counts()
-            if self.plan_ready_hook is not None:
-                self.plan_ready_hook(self.last_token_counts, dev, need_grad)
-            # the forward part of the tile lists goes up now; the backward part is written and sent
-            # once the forward launches are enqueued (the host is what the device waits for here)
-            nb, bound = info.blob_words, info.blob_words_bound
-            host = ws.bufs.get('blob_host')
-            if host is None or host.numel() < bound:
-                host = ws.bufs['blob_host'] = torch.empty(bound + bound // 4, dtype=torch.int32, pin_memory=True)
-            plan.blob_range_into(host, 0, nb)
-            hused = hp[:(N * T + 1) // 2].view(torch.float32)[:N * T].view(N, T)   # programs are parsed: reuse
-            plan.used_fns_into(hused)
-            st['blob'] = ws.get('blob', bound, torch.int32, dev)
-            # Module_Model.py:227,231: a float tensor on the program's device
-            used = torch.empty(N, T, dtype=torch.float32, device=program.device)
-            with torch.cuda.stream(side):
-                st['blob'][:nb].copy_(host[:nb], non_blocking=True)
-                if used.is_cuda:
-                    used.copy_(hused, non_blocking=True)
-                    used.record_stream(side)
-                else:
-                    used.copy_(hused)
-                ws.host_event = torch.cuda.Event()
-                ws.host_event.record(side)
-            cur.wait_event(ws.host_event)
-            self._mark('blob')
-            self.used_fns = used
-            slots = info.slots_total if need_grad else info.slots_fwd
-            arena_big = ws.get_capacity('arena', slots * HW * c, torch.bfloat16, dev)
-            if arena_big.data_ptr() != arena_full.data_ptr():     # grew: carry the stem output over
-                arena_big[:stem_elems].copy_(arena_full[:stem_elems])
-            st['arena'] = arena = arena_big[:slots * HW * c]
+            if devs:
+                sched = self._schedule_on_device(st, prog_dev, ws, arena_full, stem_elems)
+                plan = None
+            else:
+                sched = None
+                # programs -> plan -> tile lists on the device
+                if arrived is not None:
+                    arrived.synchronize()
+                plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk,
+                            (_lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED) |
+                            (_lib.PLAN_BALANCE if self.balance_levels else 0) | _lib.PLAN_DEFER_BACKWARD,
+                            image_index=image_index, num_images=M if image_index is not None else None)
+                st['plan'] = plan
+                info = plan.info
+                self.last_token_counts = plan.token_counts()
+                if self.plan_ready_hook is not None:
+                    self.plan_ready_hook(self.last_token_counts, dev, need_grad)
+                # the forward part of the tile lists goes up now; the backward part is written and sent
+                # once the forward launches are enqueued (the host is what the device waits for here)
+                nb, bound = info.blob_words, info.blob_words_bound
+                host = ws.bufs.get('blob_host')
+                if host is None or host.numel() < bound:
+                    host = ws.bufs['blob_host'] = torch.empty(bound + bound // 4, dtype=torch.int32, pin_memory=True)
+                plan.blob_range_into(host, 0, nb)
+                hused = hp[:(N * T + 1) // 2].view(torch.float32)[:N * T].view(N, T)   # programs are parsed: reuse
+                plan.used_fns_into(hused)
+                st['blob'] = ws.get('blob', bound, torch.int32, dev)
+                # Module_Model.py:227,231: a float tensor on the program's device
+                used = torch.empty(N, T, dtype=torch.float32, device=program.device)
+                with torch.cuda.stream(side):
+                    st['blob'][:nb].copy_(host[:nb], non_blocking=True)
+                    if used.is_cuda:
+                        used.copy_(hused, non_blocking=True)
+                        used.record_stream(side)
+                    else:
+                        used.copy_(hused)
+                    ws.host_event = torch.cuda.Event()
+                    ws.host_event.record(side)
+                cur.wait_event(ws.host_event)
+                self._mark('blob')
+                self.used_fns = used
+                slots = info.slots_total if need_grad else info.slots_fwd
+                arena_big = ws.get_capacity('arena', slots * HW * c, torch.bfloat16, dev)
+                if arena_big.data_ptr() != arena_full.data_ptr():     # grew: carry the stem output over
+                    arena_big[:stem_elems].copy_(arena_full[:stem_elems])
+                st['arena'] = arena = arena_big[:slots * HW * c]
         except BaseException:
             st.release()
             raise
         # module trees, level by level
-        tctx = self._tree_ctx(st, pk)
-        if fused:
-            tctx.flags |= _lib.TREE_SKIP_LEVEL0
-        _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
+        arena = st['arena']
+        if devs:
+            # a row has at most T // L nodes of level L; the launch reads the level's real tile range
+            # on the device and the workgroups beyond it exit
+            for L in range(1, T + 1):
+                ops.resblock_tiles(arena, pk['w_conv1'], pk['w_conv2'], sched.tiles, N * (T // L),
+                                   bias_first=pk['b_conv1'], bias_second=pk['b_conv2'], relu=True,
+                                   w_pre=pk['w_proj'], bias_pre=pk['b_proj'], num_pre=1,
+                                   level_info=sched.level_info, level=L)
+        else:
+            tctx = self._tree_ctx(st, pk)
+            if fused:
+                tctx.flags |= _lib.TREE_SKIP_LEVEL0
+            _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
         self._mark('tree_fwd')
         # classifier (Module_Model.py:66-93, default: no pooling): conv1x1 + ReLU on the gathered
         # roots, flatten, linear layers
@@ -712,8 +740,13 @@ class ModuleNet(nn.Module):
         st['c1'] = c1 = ws.get('c1', np128 * HW * p_, torch.bfloat16, dev)
         if np128 != N:
             c1.view(np128, HW * p_)[N:].zero_()   # padding rows feed GEMM tiles: keep them finite
-        self._conv(st, arena, c1, pk['w_cls'], 'CLS_FWD_TILES', 1, c // 128, p_, slot, (HW * p_, p_),
-                   bias=pk['b_cls'], relu=True)
+        if devs:
+            ops.conv_tiles(arena, c1, pk['w_cls'], sched.cls_tiles, N, taps=1, k_chunks=c // 128, n_out=p_,
+                           src_slot_stride=slot[0], src_pix_stride=slot[1], dst_slot_stride=HW * p_,
+                           dst_pix_stride=p_, w_group_stride=0, bias=pk['b_cls'], relu=True)
+        else:
+            self._conv(st, arena, c1, pk['w_cls'], 'CLS_FWD_TILES', 1, c // 128, p_, slot, (HW * p_, p_),
+                       bias=pk['b_cls'], relu=True)
         acts = [c1]
         prev_dim = HW * p_
         fcs = list(d['fcs']) + [d['na']]
@@ -755,6 +788,44 @@ class ModuleNet(nn.Module):
         if self.keep_state:
             self.last_state = st
         return st
+
+    def _schedule_on_device(self, st, prog_dev, ws, arena_full, stem_elems):
+        """Parse and bucket the programs where they are (vqa_devsched_build); sets the call's arena
+        (fixed slot strides: the host does not learn the node counts) and used_fns."""
+        d = self._dims
+        dev, c = prog_dev.device, d['c']
+        N, T = prog_dev.shape
+        t2i = self.vocab['program_token_to_idx']
+        nv = len(self._tokens)
+        if self._arity_dev is None or self._arity_dev.device != dev:
+            ar = np.asarray(V.arity_table(self.vocab), dtype=np.int8)
+            zero = [i for i in range(nv) if ar[i] == 0 and i != t2i['scene']]
+            if zero or ar.min() < 0 or ar.max() > 2:
+                raise ValueError('the device scheduler needs arities 1 or 2 for every token but scene')
+            self._arity_dev = torch.from_numpy(ar).to(dev)
+        sched = ops.DeviceSchedule(ws.get('devsched', ops.DeviceSchedule.words(N, T, nv), torch.int32, dev), N, T, nv)
+        # Module_Model.py:227,231: a float tensor on the program's device
+        used = torch.empty(N, T, dtype=torch.float32, device=dev)
+        ops.devsched_build(prog_dev, self._arity_dev, used, sched, t2i['<NULL>'], t2i['<START>'], t2i['scene'])
+        self.used_fns = used
+        self.schedule_error = sched.error.clone()      # the workspace is reused by later calls
+        self.last_token_counts = None
+        st['plan'], st['sched'] = None, sched
+        slots = 4 * N + 3 * N * T
+        arena_big = ws.get_capacity('arena', slots * HW * c, torch.bfloat16, dev)
+        if arena_big.data_ptr() != arena_full.data_ptr():     # grew: carry the stem output over
+            arena_big[:stem_elems].copy_(arena_full[:stem_elems])
+        st['arena'] = arena_big[:slots * HW * c]
+        return sched
+
+    def raise_for_schedule_error(self):
+        """After a forward with schedule_on_device: waits for that call's scheduling kernels and raises
+        KeyError if a program held a token id outside the vocabulary - what the reference's dict
+        lookup (Module_Model.py:200) and the host scheduler raise at once.  The logits of such a
+        call are those of a lone scene module for the offending rows."""
+        e = self.schedule_error
+        if e is not None and int(e.item()):
+            raise KeyError('program token id outside the vocabulary')
 
     def _params_changed(self):
         """Parameters are about to change without their version counters moving (a backward pass is

@@ -51,9 +51,11 @@ def conv_tiles(src, dst, w_packed, tiles, num_tiles, *, taps, k_chunks, n_out, s
 
 def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=None, bias_second=None,
                    relu=False, tiles_offset=0, w_pre=None, bias_pre=None, w_post=None, num_pre=0, num_post=0,
-                   phase_stamps=None):
+                   phase_stamps=None, level_info=None, level=0):
     """Every convolution of a 128-wide tree node, one workgroup per tile (vqa_resblock_tiles);
-    `arena` is bf16 [slots][196][128], `tiles` holds 12-word vqa_resblock_tile records."""
+    `arena` is bf16 [slots][196][128], `tiles` holds 12-word vqa_resblock_tile records.  With
+    `level_info` (device int32 [levels][2] of vqa_devsched_build) the tile range of `level` is read
+    on the device and num_tiles is an upper bound of its length."""
     _need_cuda(arena, w_first, w_second, tiles)
     p = _lib.ResblockParams()
     p.arena, p.w_first, p.w_second = arena.data_ptr(), w_first.data_ptr(), w_second.data_ptr()
@@ -67,7 +69,50 @@ def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=Non
     p.flags = (_lib.CONV_BIAS if bias_first is not None else 0) | (_lib.CONV_RELU if relu else 0)
     p.num_tiles, p.num_pre, p.num_post = num_tiles, num_pre, num_post
     p.phase_stamps = phase_stamps.data_ptr() if phase_stamps is not None else 0
+    p.level_info = level_info.data_ptr() + 8 * level if level_info is not None else 0
     _lib.check(_lib.load().vqa_resblock_tiles(C.byref(p), _stream()))
+
+
+class DeviceSchedule:
+    """Buffers of one vqa_devsched_build call, carved out of one int32 device tensor: `tiles`
+    ([N * T][12] fused tile records, level-major), `level_info` ([T + 1][2]), `cls_tiles` ([N][8]),
+    `hist` ([T + 1][V] nodes per (level, token)), `error` ([1])."""
+
+    @staticmethod
+    def words(N, T, V):
+        return N * (2 * T + 1) * 4 + N * 4 + 3 * (T + 1) * V + N * 6 * T + N * 2 + (T + 1) * 2 + N * T * 12 + N * 8 + 16
+
+    def __init__(self, buf, N, T, V):
+        assert buf.dtype == torch.int32 and buf.numel() >= self.words(N, T, V)
+        at = [0]
+
+        def take(n):
+            v = buf[at[0]:at[0] + n]
+            at[0] += (n + 1) // 2 * 2          # 8-byte alignment throughout
+            return v
+        self.N, self.T, self.V = N, T, V
+        self.tiles, self.cls_tiles = take(N * T * 12), take(N * 8)
+        self.level_info, self.hist = take((T + 1) * 2), take((T + 1) * V)
+        self.error = take(1)
+        self.node, self.counts, self.work = take(N * (2 * T + 1) * 4), take(N * 4), take(N * 6 * T)
+        self.row_base, self.bin_off, self.bin_cursor = take(N * 2), take((T + 1) * V), take((T + 1) * V)
+
+
+def devsched_build(programs, arity, used, sched, null_id, start_id, scene_id):
+    """Programs in device memory -> tile lists in device memory (vqa_devsched_build): `programs`
+    int64 [N][T], `arity` int8 [V], `used` float32 [N][T] out, `sched` a DeviceSchedule."""
+    _need_cuda(programs, arity, used, sched.tiles)
+    N, T = programs.shape
+    assert programs.dtype == torch.int64 and programs.is_contiguous() and arity.dtype == torch.int8
+    assert used.dtype == torch.float32 and used.is_contiguous() and used.shape == (N, T)
+    assert (N, T, arity.numel()) == (sched.N, sched.T, sched.V)
+    p = _lib.DevschedParams()
+    p.programs, p.arity, p.used = programs.data_ptr(), arity.data_ptr(), used.data_ptr()
+    for k in ('node', 'counts', 'hist', 'work', 'row_base', 'level_info', 'bin_off', 'bin_cursor', 'tiles',
+              'cls_tiles', 'error'):
+        setattr(p, k, getattr(sched, k).data_ptr())
+    p.N, p.T, p.V, p.null_id, p.start_id, p.scene_id = N, T, sched.V, null_id, start_id, scene_id
+    _lib.check(_lib.load().vqa_devsched_build(C.byref(p), _stream()))
 
 
 def pack_conv_weight(w, groups, n_out, k_in, taps, g_stride, n_stride, k_stride, flip=False, out=None):
