@@ -217,11 +217,11 @@ typedef struct {
     unsigned long long* phase_stamps; /* diagnostics: null, or device [num_tiles][8] shader-clock
                                    timestamps of each tile's phase boundaries */
     const int32_t* level_info;  /* null, or device {first tile, tiles}: the tile range is read on the
-                                   device (`tiles` + first tile, that many) and num_tiles is an
-                                   upper bound of its length (workgroups beyond it exit at once);
-                                   for tile lists made by vqa_devsched_build, whose sizes the host
-                                   never learns.  num_pre / num_post then only say whether such
-                                   tiles may occur */
+                                   device (`tiles` + first tile, that many) and shared by the
+                                   num_tiles workgroups of the launch, whatever its length; for tile
+                                   lists made by vqa_devsched_build, whose sizes the host never
+                                   learns.  num_pre / num_post then only say whether such tiles may
+                                   occur */
 } vqa_resblock_params;
 
 int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);
@@ -235,25 +235,26 @@ int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);
  * VQA_PLAN_BALANCE.  Slots have fixed strides (NVmax = N * T): stem maps and scene module as in
  * vqa_schedule_build (F i, S0 N+i, scene output 2N+i, scene intermediate 3N+i), other nodes
  * Y = 4N + v, H = 4N + NVmax + v, projections P = 4N + 2 NVmax + b; the arena needs 4N + 3 NVmax
- * slots.  Level L (1..T) runs as vqa_resblock_tiles with level_info + 2L over `tiles` and
- * num_tiles = N * (T / L): a node of level L has L nodes of its own below and including it, so a row
- * holds at most T / L of them.  A token id
+ * slots.  Level L (1..T) runs as vqa_resblock_tiles with level_info + 2L over `tiles` (a node of
+ * level L has L nodes of its own below and including it, so a row holds at most T / L of them: no
+ * more than N * (T / L) workgroups are of use).  A token id
  * outside [0, V) sets *error to 1 (the host scheduler's VQA_EVOCAB) and the row runs as a lone scene.
+ * Limits: V <= 255, T <= 1023, N * T < 2^26, and programs short enough for a row's parse state
+ * (52 T + 16 bytes) to fit LDS; VQA_EINVAL beyond them.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     const int64_t* programs;  /* device [N][T] token ids */
     const int8_t* arity;      /* device [V]; 0 for the scene token only */
     float* used;              /* device out [N][T]: Module_Model.py:227,231 used_fns */
-    int32_t* node;            /* device workspace [N][2T+1][4] */
-    int32_t* counts;          /* device workspace [N][4] */
+    int32_t* node;            /* device workspace [N][2T+1][4], 16-byte aligned */
+    int32_t* counts;          /* device workspace [N][4], 16-byte aligned */
     int32_t* hist;            /* device out [T+1][V]: nodes per (level, token) */
-    int32_t* work;            /* device workspace [N][6T] */
     int32_t* row_base;        /* device workspace [N][2] */
     int32_t* level_info;      /* device out [T+1][2]: first tile, tiles of each level */
     int32_t* bin_off;         /* device workspace [T+1][V] */
     int32_t* bin_cursor;      /* device workspace [T+1][V] */
-    int32_t* tiles;           /* device out [N*T][12]: vqa_resblock_tile records, level-major */
-    int32_t* cls_tiles;       /* device out [N][8]: vqa_conv_tile records of the classifier's gather */
+    int32_t* tiles;           /* device out [N*T][12]: vqa_resblock_tile records, level-major; 16-byte aligned */
+    int32_t* cls_tiles;       /* device out [N][8]: vqa_conv_tile records of the classifier's gather; 16-byte aligned */
     int32_t* error;           /* device out [1] */
     int32_t N, T, V, null_id, start_id, scene_id;
 } vqa_devsched_params;

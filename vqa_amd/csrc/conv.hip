@@ -352,18 +352,19 @@ __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase
     }
 }
 
+// RANGE false: one tile per workgroup, entry blockIdx.x of the list in XCD order.  RANGE true: the
+// tile range is in device memory (`level_info`: first tile, tiles) and the workgroups of the launch,
+// however many, share it; every workgroup leaves its loop, with or without work.
+template <bool RANGE>
 __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_params p) {
     extern __shared__ __attribute__((aligned(16))) char halo[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    // the tile: entry blockIdx.x of the list in XCD order, or, with the range in device memory
-    // (`level_info`: first tile, tiles), entry first + blockIdx.x if there is one
-    const vqa_resblock_tile* tp = p.tiles + xcd_tile_index(blockIdx.x, p.num_tiles);
-    if (p.level_info) {
-        if ((int)blockIdx.x >= p.level_info[1]) return;
-        tp = p.tiles + p.level_info[0] + blockIdx.x;
-    }
-    const vqa_resblock_tile t = *tp;
+    int tile_i = RANGE ? p.level_info[0] + (int)blockIdx.x : xcd_tile_index(blockIdx.x, p.num_tiles);
+    const int tile_end = RANGE ? p.level_info[0] + p.level_info[1] : 0;
+    if (RANGE && tile_i >= tile_end) return;
+    do {
+    const vqa_resblock_tile t = p.tiles[tile_i];
     // diagnostics: shader-clock timestamps of the phase boundaries of every tile
     unsigned long long* stamps = p.phase_stamps ? p.phase_stamps + (int64_t)blockIdx.x * 8 : nullptr;
 #define STAMP(i) if (stamps && tid == 0) stamps[i] = __builtin_readcyclecounter()
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
                   t.res >= 0 ? arena + (int64_t)t.res * slot_b : nullptr,
                   t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, d0, 128, tid);
     STAMP(6);
-    if (!post) return;
+    if (post) {
 
     // binary node, backward: the map just stored (dP) goes through the transposed 1x1 projection,
     // 256 outputs = one pass per child; the epilogue staging destroys the image, so it is staged
@@ -447,6 +448,9 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
                      arena + (int64_t)dslot * slot_b, tid);
     }
     STAMP(7);
+    }
+    if (RANGE) __syncthreads();     // the next tile's staging overwrites the image this one's epilogue reads
+    } while (RANGE && (tile_i += (int)gridDim.x) < tile_end);
 #undef STAMP
 }
 
@@ -487,14 +491,16 @@ extern "C" int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream) {
     if (p->num_tiles == 0) return VQA_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)resblock_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+        (void)hipFuncSetAttribute((const void*)resblock_tiles_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+        (void)hipFuncSetAttribute((const void*)resblock_tiles_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
         attr_set = true;
     }
     // two 3x3 convolutions of 128 -> 128 channels per tile, plus the 1x1 projection of binary nodes
     VqaProfScope prof(VQA_K_RESBLOCK, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles +
                                           2.0 * VQA_HW * 256.0 * 128.0 * (p->num_pre + p->num_post),
                       (double)p->num_tiles * VQA_HW * 2.0 * 128 * 3, (hipStream_t)stream);
-    hipLaunchKernelGGL(resblock_tiles_kernel, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
+    if (p->level_info) hipLaunchKernelGGL(resblock_tiles_kernel<true>, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(resblock_tiles_kernel<false>, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_resblock_tiles: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;

@@ -7,183 +7,256 @@
 // host scheduler produces without VQA_PLAN_BALANCE, so results are bit-identical to it.
 //
 // The host never learns the node counts: the arena uses fixed strides (a row has at most T nodes
-// that are not the scene module), the launch of level L has N * (T / L) workgroups - a row's upper
-// bound - which take the level's tile range from device memory and exit when they are beyond it
-// (vqa_resblock_tiles with `level_info`), and a token id
-// outside the vocabulary - a KeyError in the reference and in the host scheduler - raises a flag in
-// device memory instead (the row then runs as a lone scene module).
+// that are not the scene module), the launch of a level has a fixed number of workgroups which
+// share the level's tile range, read from device memory (vqa_resblock_tiles with `level_info`), and
+// a token id outside the vocabulary - a KeyError in the reference and in the host scheduler - raises
+// a flag in device memory instead (the row then runs as a lone scene module).
+//
+// A parse is a chain of dependent reads and writes, one short step per token: it runs one row per
+// lane with all of its state in LDS (a round trip to HBM per step would cost 100 times the step).
 #include <string>
 
 #include "vqa_dev.h"
 #include "plan.h"
 
-// One thread per program row.  Iterative form of the recursive helper: a stack of open nodes that
-// wait for inputs (in `work`), finished nodes appended in execution (post-)order.
-//   node  [N][2T+1][4] : token, input 0, input 1 (indices into the row's node list, -1 none), level
-//   counts[N][4]       : nodes, nodes that are not the scene module, binary nodes, root's index
-//   hist  [T+1][V]     : nodes that are not the scene module per (level, token), whole batch (atomic)
-//   work  [N][T][6]    : scratch (pending nodes and the stack)
-__global__ __launch_bounds__(256) void devsched_parse_kernel(vqa_devsched_params p) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= p.N) return;
-    const int T = p.T, R = 2 * T + 1;
-    const int64_t* prog = p.programs + (int64_t)row * T;
-    float* used = p.used + (int64_t)row * T;
-    int32_t* node = p.node + (int64_t)row * R * 4;
-    int32_t* pend = p.work + (int64_t)row * T * 6;          // [T][4] pending nodes, then [T][2] stack frames
-    int32_t* stack = pend + T * 4;
-    for (int j = 0; j < T; j++) used[j] = 0.f;
-    int j = 0, n = 0, np = 0, sp = 0, root = 0;
-    bool bad = false;
-    for (;;) {
-        int tok;
+#define USED_BIT (1 << 30)
+
+// node record, 4 words: token | level << 8, input 0, input 1 (indices into the row's node list, -1
+// none), rank among the row's nodes that are not the scene module | rank among its binary nodes << 16
+//
+// One lane per program row.  Iterative form of the recursive helper: a stack of open nodes that
+// wait for inputs, finished nodes appended in execution (post-)order.  LDS, lane-minor:
+//   toks [T][B]     the rows' tokens (-1: outside the vocabulary), USED_BIT once marked used
+//   pend [T][3][B]  open nodes: token | level << 8, input 0, input 1
+//   stack[T][B]     open node | inputs still missing << 16
+//   node [2T+1][4][B]
+//   arity[V]
+__global__ __launch_bounds__(64) void devsched_parse_kernel(vqa_devsched_params p) {
+    extern __shared__ int32_t lds[];
+    const int T = p.T, B = blockDim.x, t = threadIdx.x;
+    int32_t* toks = lds;
+    int32_t* pend = toks + T * B;
+    int32_t* stack = pend + 3 * T * B;
+    int32_t* node = stack + T * B;
+    int32_t* arity = node + (2 * T + 1) * 4 * B;     // [V]
+    for (int i = t; i < p.V; i += B) arity[i] = p.arity[i];
+    const int row0 = blockIdx.x * B, row = row0 + t;
+    for (int idx = t; idx < B * T; idx += B) {
+        const int r = idx / T, j = idx - r * T;
+        int tok = p.null_id;
+        if (row0 + r < p.N) {
+            const int64_t v = p.programs[(int64_t)(row0 + r) * T + j];
+            tok = (v < 0 || v >= p.V) ? -1 : (int)v;
+        }
+        toks[j * B + r] = tok;
+    }
+    __syncthreads();
+    if (row < p.N) {
+        int j = 0, n = 0, np = 0, sp = 0, root = 0;
+        bool bad = false;
         for (;;) {
-            if (j < T) {
-                const int64_t v = prog[j];
-                if (v < 0 || v >= p.V) { bad = true; break; }
-                tok = (int)v;
-                if (tok == p.start_id) { j++; continue; }          // skipped, wherever it stands
-                if (tok != p.null_id) used[j] = 1.f;               // <NULL> runs as a module but is not marked
-                j++;
-            } else {
-                tok = p.scene_id;                                  // reading past the row: an implicit scene
-            }
-            break;
-        }
-        if (bad) break;
-        const int ar = tok == p.scene_id ? 0 : p.arity[tok];
-        if (ar == 0) {
-            int id = n++;
-            node[id * 4 + 0] = tok; node[id * 4 + 1] = -1; node[id * 4 + 2] = -1; node[id * 4 + 3] = 0;
-            bool done = false;
+            int tok;
             for (;;) {
-                if (sp == 0) { root = id; done = true; break; }
-                int32_t* f = stack + (sp - 1) * 2;
-                int32_t* par = pend + f[0] * 4;
-                if (par[1] < 0) par[1] = id; else par[2] = id;
-                par[3] = max(par[3], node[id * 4 + 3] + 1);
-                if (--f[1] > 0) break;
-                sp--;
-                id = n++;
-                node[id * 4 + 0] = par[0]; node[id * 4 + 1] = par[1]; node[id * 4 + 2] = par[2]; node[id * 4 + 3] = par[3];
+                if (j < T) {
+                    tok = toks[j * B + t];
+                    if (tok < 0) { bad = true; break; }
+                    if (tok == p.start_id) { j++; continue; }                    // skipped, wherever it stands
+                    if (tok != p.null_id) toks[j * B + t] = tok | USED_BIT;      // <NULL> runs as a module but is not marked
+                    j++;
+                } else {
+                    tok = p.scene_id;                                            // reading past the row: an implicit scene
+                }
+                break;
             }
-            if (done) break;
-        } else {
-            int32_t* q = pend + np * 4;
-            q[0] = tok; q[1] = -1; q[2] = -1; q[3] = 0;
-            stack[sp * 2] = np++; stack[sp * 2 + 1] = ar;
-            sp++;
+            if (bad) break;
+            const int ar = tok == p.scene_id ? 0 : arity[tok];
+            if (ar == 0) {
+                int id = n++;
+                int lvl = 0;
+                int32_t* nd = node + id * 4 * B + t;
+                nd[0] = tok; nd[B] = -1; nd[2 * B] = -1;
+                bool done = false;
+                for (;;) {
+                    if (sp == 0) { root = id; done = true; break; }
+                    const int f = stack[(sp - 1) * B + t];
+                    const int pi = f & 0xffff, need = (f >> 16) - 1;
+                    int32_t* par = pend + pi * 3 * B + t;
+                    if (par[B] < 0) par[B] = id; else par[2 * B] = id;
+                    const int ptok = par[0] & 255, plvl = max(par[0] >> 8, lvl + 1);
+                    par[0] = ptok | plvl << 8;
+                    if (need > 0) { stack[(sp - 1) * B + t] = pi | need << 16; break; }
+                    sp--;
+                    id = n++;
+                    lvl = plvl;
+                    nd = node + id * 4 * B + t;
+                    nd[0] = par[0]; nd[B] = par[B]; nd[2 * B] = par[2 * B];
+                }
+                if (done) break;
+            } else {
+                int32_t* q = pend + np * 3 * B + t;
+                q[0] = tok; q[B] = -1; q[2 * B] = -1;
+                stack[sp * B + t] = np | ar << 16;
+                np++; sp++;
+            }
         }
+        if (bad) {
+            atomicOr(p.error, 1);
+            for (int c = 0; c < T; c++) toks[c * B + t] = 0;
+            n = 1; root = 0;
+            node[t] = p.scene_id; node[B + t] = -1; node[2 * B + t] = -1;
+        }
+        int nv = 0, nb = 0;
+        int4* out = (int4*)p.node + (int64_t)row * (2 * T + 1);
+        for (int k = 0; k < n; k++) {
+            const int32_t* nd = node + k * 4 * B + t;
+            const int w0 = nd[0], c0 = nd[B], c1 = nd[2 * B];
+            out[k] = make_int4(w0, c0, c1, nv | nb << 16);
+            if ((w0 & 255) == p.scene_id) continue;
+            nv++;
+            nb += c1 >= 0;
+            atomicAdd(p.hist + (w0 >> 8) * p.V + (w0 & 255), 1);
+        }
+        *((int4*)p.counts + row) = make_int4(n, nv, nb, root);
     }
-    if (bad) {
-        atomicOr(p.error, 1);
-        for (int c = 0; c < T; c++) used[c] = 0.f;
-        n = 1; root = 0;
-        node[0] = p.scene_id; node[1] = -1; node[2] = -1; node[3] = 0;
+    __syncthreads();
+    for (int idx = t; idx < B * T; idx += B) {
+        const int r = idx / T, j = idx - r * T;
+        if (row0 + r < p.N) p.used[(int64_t)(row0 + r) * T + j] = (toks[j * B + r] & USED_BIT) ? 1.f : 0.f;
     }
-    int nv = 0, nb = 0;
-    for (int k = 0; k < n; k++) {
-        const int tok = node[k * 4];
-        if (tok == p.scene_id) continue;
-        nv++;
-        nb += node[k * 4 + 2] >= 0;
-        atomicAdd(p.hist + node[k * 4 + 3] * p.V + tok, 1);
+}
+
+// exclusive scan of one value per thread over the workgroup (1024 threads)
+__device__ __forceinline__ int block_exclusive_scan(int v, int* buf) {
+    const int tid = threadIdx.x;
+    buf[tid] = v;
+    __syncthreads();
+    int acc = v;
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int other = tid >= d ? buf[tid - d] : 0;
+        __syncthreads();
+        acc += other;
+        buf[tid] = acc;
+        __syncthreads();
     }
-    int32_t* c = p.counts + row * 4;
-    c[0] = n; c[1] = nv; c[2] = nb; c[3] = root;
+    return acc - v;
 }
 
 // One workgroup: exclusive scans.  Rows -> first global index of the row's non-scene nodes and of
 // its binary nodes; (level, token) bins in level-major order -> first tile of each bin, and per
 // level {first tile, tiles} for the launches.  Also clears the bin cursors.
 __global__ __launch_bounds__(1024) void devsched_scan_kernel(vqa_devsched_params p) {
-    __shared__ int part[1024];
-    __shared__ int part_b[1024];
+    extern __shared__ int32_t lds[];      // [(T+1) * V] histogram, then [T+1] level sums
+    __shared__ int buf[1024];
     const int tid = threadIdx.x;
-    // rows: each thread owns a contiguous run
     const int per = (p.N + 1023) / 1024;
+    const int lo = min(p.N, tid * per), hi = min(p.N, lo + per);
     int sv = 0, sb = 0;
-    for (int r = tid * per; r < min(p.N, (tid + 1) * per); r++) { sv += p.counts[r * 4 + 1]; sb += p.counts[r * 4 + 2]; }
-    part[tid] = sv; part_b[tid] = sb;
+    for (int r = lo; r < hi; r++) { sv += p.counts[r * 4 + 1]; sb += p.counts[r * 4 + 2]; }
+    int av = block_exclusive_scan(sv, buf);
     __syncthreads();
-    if (tid == 0) {
-        int av = 0, ab = 0;
-        for (int i = 0; i < 1024; i++) { const int v = part[i], b = part_b[i]; part[i] = av; part_b[i] = ab; av += v; ab += b; }
-    }
-    __syncthreads();
-    int av = part[tid], ab = part_b[tid];
-    for (int r = tid * per; r < min(p.N, (tid + 1) * per); r++) {
+    int ab = block_exclusive_scan(sb, buf);
+    for (int r = lo; r < hi; r++) {
         p.row_base[r * 2] = av; p.row_base[r * 2 + 1] = ab;
         av += p.counts[r * 4 + 1]; ab += p.counts[r * 4 + 2];
     }
-    // bins: level-major; thread L sums its level, thread 0 scans the levels, thread L scans its bins
-    const int levels = p.T + 1;
+    const int levels = p.T + 1, bins = levels * p.V;
+    int32_t* lsum = lds + bins;
+    for (int i = tid; i < bins; i += 1024) lds[i] = p.hist[i];
     __syncthreads();
     if (tid < levels) {
         int s = 0;
-        for (int t = 0; t < p.V; t++) s += p.hist[tid * p.V + t];
-        part[tid] = s;
+        for (int t = 0; t < p.V; t++) s += lds[tid * p.V + t];
+        lsum[tid] = s;
     }
     __syncthreads();
     if (tid == 0) {
         int a = 0;
-        for (int L = 0; L < levels; L++) { const int c = part[L]; p.level_info[L * 2] = a; p.level_info[L * 2 + 1] = c; a += c; }
+        for (int L = 0; L < levels; L++) { const int c = lsum[L]; lsum[L] = a; p.level_info[L * 2] = a; p.level_info[L * 2 + 1] = c; a += c; }
     }
     __syncthreads();
     if (tid < levels) {
-        int a = p.level_info[tid * 2];
-        for (int t = 0; t < p.V; t++) { const int c = p.hist[tid * p.V + t]; p.bin_off[tid * p.V + t] = a; p.bin_cursor[tid * p.V + t] = 0; a += c; }
+        int a = lsum[tid];
+        for (int t = 0; t < p.V; t++) { const int c = lds[tid * p.V + t]; lds[tid * p.V + t] = a; a += c; }
     }
+    __syncthreads();
+    for (int i = tid; i < bins; i += 1024) { p.bin_off[i] = lds[i]; p.bin_cursor[i] = 0; }
 }
 
-// One thread per row again: arena slots and the tile records.  Slots with fixed strides (NVmax =
-// N * T): F(i) = i, S0(i) = M + i, Ysc(i) = 2M + i, Hsc(i) = 3M + i, Y(v) = 4M + v,
-// H(v) = 4M + NVmax + v, P(b) = 4M + 2 NVmax + b.  A node's tile goes into its (level, token) bin
+// One thread per (row, node): arena slots and the tile record.  Slots with fixed strides (NVmax =
+// N * T): F(i) = i, S0(i) = N + i, scene output 2N + i, scene intermediate 3N + i, Y(v) = 4N + v,
+// H(v) = 4N + NVmax + v, P(b) = 4N + 2 NVmax + b.  A node's tile goes into its (level, token) bin
 // at a position taken with an atomic: the order inside a bin varies from run to run, the tiles of
 // a launch are independent of each other, so results do not.
 __global__ __launch_bounds__(256) void devsched_emit_kernel(vqa_devsched_params p) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= p.N) return;
-    const int T = p.T, R = 2 * T + 1, M = p.N;
-    const int nvmax = p.N * T;
-    const int32_t* node = p.node + (int64_t)row * R * 4;
-    int32_t* yslot = p.work + (int64_t)row * T * 6;         // the parse scratch is free now; 2T + 1 <= 6T
-    const int n = p.counts[row * 4];
-    int v = p.row_base[row * 2], b = p.row_base[row * 2 + 1];
-    for (int k = 0; k < n; k++) {
-        const int tok = node[k * 4], c0 = node[k * 4 + 1], c1 = node[k * 4 + 2], L = node[k * 4 + 3];
-        if (tok == p.scene_id) { yslot[k] = 2 * M + row; continue; }
-        const int y = 4 * M + v, h = 4 * M + nvmax + v;
-        yslot[k] = y;
-        const bool bin = c1 >= 0;
-        const int in = bin ? 4 * M + 2 * nvmax + b : yslot[c0];
-        const int pos = p.bin_off[L * p.V + tok] + atomicAdd(p.bin_cursor + L * p.V + tok, 1);
-        int32_t* t = p.tiles + (int64_t)pos * 12;
-        t[0] = bin ? yslot[c0] : in; t[1] = bin ? yslot[c1] : -1; t[2] = y; t[3] = h; t[4] = in;
-        t[5] = -1; t[6] = -1; t[7] = tok; t[8] = -1; t[9] = -1; t[10] = -1; t[11] = -1;
-        v++; b += bin;
+    const int R = 2 * p.T + 1;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)p.N * R) return;
+    const int row = (int)(gid / R), k = (int)(gid - (int64_t)row * R);
+    const int4 cnt = *((const int4*)p.counts + row);
+    if (k >= cnt.x) return;
+    const int4* nodes = (const int4*)p.node + (int64_t)row * R;
+    const int4 nd = nodes[k];
+    const int N = p.N, nvmax = p.N * p.T;
+    const int tok = nd.x & 255, L = nd.x >> 8;
+    const int vbase = p.row_base[row * 2], bbase = p.row_base[row * 2 + 1];
+    const bool scene = tok == p.scene_id;
+    const int y = scene ? 2 * N + row : 4 * N + vbase + (nd.w & 0xffff);
+    if (k == cnt.w) {
+        // the classifier's gather: root map of the row -> row of the classifier input (the torch.cat
+        // of Module_Model.py:232)
+        int4* ct = (int4*)p.cls_tiles + (int64_t)row * 2;
+        ct[0] = make_int4(y, -1, row, -1);
+        ct[1] = make_int4(-1, -1, -1, 0);
     }
-    // the classifier's gather: root map of the row -> row of the classifier input (the torch.cat of
-    // Module_Model.py:232)
-    int32_t* ct = p.cls_tiles + (int64_t)row * 8;
-    ct[0] = yslot[p.counts[row * 4 + 3]]; ct[1] = -1; ct[2] = row; ct[3] = -1; ct[4] = -1; ct[5] = -1; ct[6] = -1; ct[7] = 0;
+    if (scene) return;
+    const int4 k0 = nodes[nd.y];
+    const int y0 = (k0.x & 255) == p.scene_id ? 2 * N + row : 4 * N + vbase + (k0.w & 0xffff);
+    const bool bin = nd.z >= 0;
+    int y1 = -1;
+    if (bin) {
+        const int4 k1 = nodes[nd.z];
+        y1 = (k1.x & 255) == p.scene_id ? 2 * N + row : 4 * N + vbase + (k1.w & 0xffff);
+    }
+    const int in = bin ? 4 * N + 2 * nvmax + bbase + (nd.w >> 16) : y0;
+    const int pos = p.bin_off[L * p.V + tok] + atomicAdd(p.bin_cursor + L * p.V + tok, 1);
+    int4* t = (int4*)p.tiles + (int64_t)pos * 3;
+    t[0] = make_int4(y0, y1, y, y + nvmax);
+    t[1] = make_int4(in, -1, -1, tok);
+    t[2] = make_int4(-1, -1, -1, -1);
 }
 
 extern "C" int vqa_devsched_build(const vqa_devsched_params* p, void* stream) {
-    if (!p || !p->programs || !p->arity || !p->used || !p->node || !p->counts || !p->hist || !p->work || !p->row_base ||
+    if (!p || !p->programs || !p->arity || !p->used || !p->node || !p->counts || !p->hist || !p->row_base ||
         !p->level_info || !p->bin_off || !p->bin_cursor || !p->tiles || !p->cls_tiles || !p->error || p->N <= 0 ||
-        p->T <= 0 || p->V <= 0 || p->T + 1 > 1024) {
-        vqa_set_error("vqa_devsched_build: bad argument");
+        p->T <= 0 || p->V <= 0 || p->V > 255 || p->T + 1 > 1024 || (int64_t)p->N * p->T >= (1 << 26) ||
+        (((uintptr_t)p->node | (uintptr_t)p->counts | (uintptr_t)p->tiles | (uintptr_t)p->cls_tiles) & 15)) {
+        vqa_set_error("vqa_devsched_build: bad argument (sizes, null pointer, or node / counts / tiles / cls_tiles not 16-byte aligned)");
         return VQA_EINVAL;
+    }
+    // rows per workgroup of the parse: as many as LDS holds, 64 at most
+    const size_t per_row = ((size_t)5 * p->T + 4 * (2 * (size_t)p->T + 1)) * sizeof(int32_t);
+    int rows = 64;
+    const size_t fixed = 256 * sizeof(int32_t);      // the arity table
+    while (rows > 1 && rows * per_row + fixed > 144 * 1024) rows >>= 1;
+    const size_t scan_lds = ((size_t)(p->T + 1) * p->V + p->T + 1) * sizeof(int32_t);
+    if (rows * per_row + fixed > 144 * 1024 || scan_lds > 60 * 1024) {
+        vqa_set_error("vqa_devsched_build: programs too long for the device scheduler");
+        return VQA_EINVAL;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)devsched_parse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void*)devsched_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        attr_set = true;
     }
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(p->hist, 0, (size_t)(p->T + 1) * p->V * sizeof(int32_t), s);
     if (e == hipSuccess) e = hipMemsetAsync(p->error, 0, sizeof(int32_t), s);
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_devsched_build: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
-    const int blocks = (p->N + 255) / 256;
-    hipLaunchKernelGGL(devsched_parse_kernel, dim3(blocks), dim3(256), 0, s, *p);
-    hipLaunchKernelGGL(devsched_scan_kernel, dim3(1), dim3(1024), 0, s, *p);
-    hipLaunchKernelGGL(devsched_emit_kernel, dim3(blocks), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(devsched_parse_kernel, dim3((p->N + rows - 1) / rows), dim3(rows), rows * per_row + fixed, s, *p);
+    hipLaunchKernelGGL(devsched_scan_kernel, dim3(1), dim3(1024), scan_lds, s, *p);
+    const int64_t threads = (int64_t)p->N * (2 * p->T + 1);
+    hipLaunchKernelGGL(devsched_emit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, *p);
     e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_devsched_build: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;

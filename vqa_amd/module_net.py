@@ -252,6 +252,7 @@ class ModuleNet(nn.Module):
         # token id outside the vocabulary cannot raise from an asynchronous launch: it sets
         # schedule_error (see raise_for_schedule_error)
         self.schedule_on_device = False
+        self.device_level_workgroups = 512     # two per CU: all resident at once
         self.schedule_error = None
         self._arity_dev = None
         self.keep_state = False       # tests: keep the last call's buffers in self.last_state
@@ -599,8 +600,17 @@ class ModuleNet(nn.Module):
             devs = (self.schedule_on_device and fused and not need_grad and image_index is None and
                     program.is_cuda and program.device == dev)
             if devs:
-                prog_dev = program.detach().to(torch.int64).contiguous()      # stays where it is
+                # the programs stay where they are: parsed and bucketed by kernels on the side stream,
+                # under the stem
+                prog_dev = program.detach().to(torch.int64).contiguous()
                 arrived = None
+                sched, used = self._device_schedule_buffers(ws, N, T, dev)
+                t2i = self.vocab['program_token_to_idx']
+                with torch.cuda.stream(side):
+                    ops.devsched_build(prog_dev, self._arity_dev, used, sched, t2i['<NULL>'], t2i['<START>'], t2i['scene'])
+                    sched_done = torch.cuda.Event()
+                    sched_done.record(side)
+                prog_dev.record_stream(side)
             elif program.is_cuda:
                 prog_dev = program.detach().to(torch.int64).contiguous()
                 with torch.cuda.stream(side):
@@ -617,7 +627,10 @@ class ModuleNet(nn.Module):
             # stem: two conv3x3 + bias + ReLU over the whole batch (Module_Model.py:55-64,239)
             slot = (HW * c, c)
             stem_elems = 4 * M * HW * c      # stem maps S0, F and the scene module's H, Y per image
-            arena_full = ws.get_capacity('arena', stem_elems, torch.bfloat16, dev)
+            # (with the schedule made on the device the host does not learn the node counts: slots
+            # have fixed strides, a row has at most T nodes that are not the scene module)
+            dev_slots = 4 * N + 3 * N * T
+            arena_full = ws.get_capacity('arena', dev_slots * HW * c if devs else stem_elems, torch.bfloat16, dev)
             xn, rows, xs = self._stem_input(x, ws, M, dev)
             st['x_nhwc'], st['x_rows'] = xn, rows
             stem_tiles = self._stem_tiles(M, dev)
@@ -670,8 +683,13 @@ class ModuleNet(nn.Module):
 
             self._mark('scene')
             if devs:
-                sched = self._schedule_on_device(st, prog_dev, ws, arena_full, stem_elems)
-                plan = None
+                cur.wait_event(sched_done)
+                # Module_Model.py:227,231: a float tensor on the program's device
+                self.used_fns = used
+                self.schedule_error = sched.error.clone()      # the workspace is reused by later calls
+                self.last_token_counts = None
+                st['plan'] = plan = None
+                st['arena'] = arena_full[:dev_slots * HW * c]
             else:
                 sched = None
                 # programs -> plan -> tile lists on the device
@@ -721,10 +739,11 @@ class ModuleNet(nn.Module):
         # module trees, level by level
         arena = st['arena']
         if devs:
-            # a row has at most T // L nodes of level L; the launch reads the level's real tile range
-            # on the device and the workgroups beyond it exit
+            # the launch reads the level's tile range on the device and its workgroups share it; a row
+            # has at most T // L nodes of level L, so more workgroups than that are never of use
             for L in range(1, T + 1):
-                ops.resblock_tiles(arena, pk['w_conv1'], pk['w_conv2'], sched.tiles, N * (T // L),
+                ops.resblock_tiles(arena, pk['w_conv1'], pk['w_conv2'], sched.tiles,
+                                   min(N * (T // L), self.device_level_workgroups),
                                    bias_first=pk['b_conv1'], bias_second=pk['b_conv2'], relu=True,
                                    w_pre=pk['w_proj'], bias_pre=pk['b_proj'], num_pre=1,
                                    level_info=sched.level_info, level=L)
@@ -789,12 +808,9 @@ class ModuleNet(nn.Module):
             self.last_state = st
         return st
 
-    def _schedule_on_device(self, st, prog_dev, ws, arena_full, stem_elems):
-        """Parse and bucket the programs where they are (vqa_devsched_build); sets the call's arena
-        (fixed slot strides: the host does not learn the node counts) and used_fns."""
-        d = self._dims
-        dev, c = prog_dev.device, d['c']
-        N, T = prog_dev.shape
+    def _device_schedule_buffers(self, ws, N, T, dev):
+        """Workspace of vqa_devsched_build for N programs of T tokens, the arity table on the device,
+        and a fresh used_fns tensor."""
         t2i = self.vocab['program_token_to_idx']
         nv = len(self._tokens)
         if self._arity_dev is None or self._arity_dev.device != dev:
@@ -804,19 +820,7 @@ class ModuleNet(nn.Module):
                 raise ValueError('the device scheduler needs arities 1 or 2 for every token but scene')
             self._arity_dev = torch.from_numpy(ar).to(dev)
         sched = ops.DeviceSchedule(ws.get('devsched', ops.DeviceSchedule.words(N, T, nv), torch.int32, dev), N, T, nv)
-        # Module_Model.py:227,231: a float tensor on the program's device
-        used = torch.empty(N, T, dtype=torch.float32, device=dev)
-        ops.devsched_build(prog_dev, self._arity_dev, used, sched, t2i['<NULL>'], t2i['<START>'], t2i['scene'])
-        self.used_fns = used
-        self.schedule_error = sched.error.clone()      # the workspace is reused by later calls
-        self.last_token_counts = None
-        st['plan'], st['sched'] = None, sched
-        slots = 4 * N + 3 * N * T
-        arena_big = ws.get_capacity('arena', slots * HW * c, torch.bfloat16, dev)
-        if arena_big.data_ptr() != arena_full.data_ptr():     # grew: carry the stem output over
-            arena_big[:stem_elems].copy_(arena_full[:stem_elems])
-        st['arena'] = arena_big[:slots * HW * c]
-        return sched
+        return sched, torch.empty(N, T, dtype=torch.float32, device=dev)
 
     def raise_for_schedule_error(self):
         """After a forward with schedule_on_device: waits for that call's scheduling kernels and raises

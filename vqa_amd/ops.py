@@ -55,7 +55,7 @@ def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=Non
     """Every convolution of a 128-wide tree node, one workgroup per tile (vqa_resblock_tiles);
     `arena` is bf16 [slots][196][128], `tiles` holds 12-word vqa_resblock_tile records.  With
     `level_info` (device int32 [levels][2] of vqa_devsched_build) the tile range of `level` is read
-    on the device and num_tiles is an upper bound of its length."""
+    on the device and shared by the num_tiles workgroups of the launch."""
     _need_cuda(arena, w_first, w_second, tiles)
     p = _lib.ResblockParams()
     p.arena, p.w_first, p.w_second = arena.data_ptr(), w_first.data_ptr(), w_second.data_ptr()
@@ -80,7 +80,7 @@ class DeviceSchedule:
 
     @staticmethod
     def words(N, T, V):
-        return N * (2 * T + 1) * 4 + N * 4 + 3 * (T + 1) * V + N * 6 * T + N * 2 + (T + 1) * 2 + N * T * 12 + N * 8 + 16
+        return N * (2 * T + 1) * 4 + N * 4 + 3 * (T + 1) * V + N * 2 + (T + 1) * 2 + N * T * 12 + N * 8 + 4 + 4 * 10
 
     def __init__(self, buf, N, T, V):
         assert buf.dtype == torch.int32 and buf.numel() >= self.words(N, T, V)
@@ -88,13 +88,13 @@ class DeviceSchedule:
 
         def take(n):
             v = buf[at[0]:at[0] + n]
-            at[0] += (n + 1) // 2 * 2          # 8-byte alignment throughout
+            at[0] += (n + 3) // 4 * 4          # 16-byte alignment throughout
             return v
         self.N, self.T, self.V = N, T, V
         self.tiles, self.cls_tiles = take(N * T * 12), take(N * 8)
         self.level_info, self.hist = take((T + 1) * 2), take((T + 1) * V)
         self.error = take(1)
-        self.node, self.counts, self.work = take(N * (2 * T + 1) * 4), take(N * 4), take(N * 6 * T)
+        self.node, self.counts = take(N * (2 * T + 1) * 4), take(N * 4)
         self.row_base, self.bin_off, self.bin_cursor = take(N * 2), take((T + 1) * V), take((T + 1) * V)
 
 
@@ -108,7 +108,7 @@ def devsched_build(programs, arity, used, sched, null_id, start_id, scene_id):
     assert (N, T, arity.numel()) == (sched.N, sched.T, sched.V)
     p = _lib.DevschedParams()
     p.programs, p.arity, p.used = programs.data_ptr(), arity.data_ptr(), used.data_ptr()
-    for k in ('node', 'counts', 'hist', 'work', 'row_base', 'level_info', 'bin_off', 'bin_cursor', 'tiles',
+    for k in ('node', 'counts', 'hist', 'row_base', 'level_info', 'bin_off', 'bin_cursor', 'tiles',
               'cls_tiles', 'error'):
         setattr(p, k, getattr(sched, k).data_ptr())
     p.N, p.T, p.V, p.null_id, p.start_id, p.scene_id = N, T, sched.V, null_id, start_id, scene_id
