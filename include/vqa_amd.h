@@ -231,8 +231,7 @@ int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);
  * vqa_schedule_build for programs that are in device memory (the sampler builds them there,
  * LSTM_Model.py:205-235), without the copy to the host that forward_modules_ints_helper
  * (Module_Model.py:196-222) and its caller (Train_model.py:339-354) start with.  Same parse rules,
- * same earliest-level schedule, hence the same logits bit for bit as the host scheduler without
- * VQA_PLAN_BALANCE.  Slots have fixed strides (NVmax = N * T): stem maps and scene module as in
+ * hence the same trees and the same logits bit for bit as the host scheduler's.  Slots have fixed strides (NVmax = N * T): stem maps and scene module as in
  * vqa_schedule_build (F i, S0 N+i, scene output 2N+i, scene intermediate 3N+i), other nodes
  * Y = 4N + v, H = 4N + NVmax + v, projections P = 4N + 2 NVmax + b; the arena needs 4N + 3 NVmax
  * slots.  Level L (1..T) runs as vqa_resblock_tiles with level_info + 2L over `tiles` (a node of
@@ -255,8 +254,13 @@ typedef struct {
     int32_t* bin_cursor;      /* device workspace [T+1][V] */
     int32_t* tiles;           /* device out [N*T][12]: vqa_resblock_tile records, level-major; 16-byte aligned */
     int32_t* cls_tiles;       /* device out [N][8]: vqa_conv_tile records of the classifier's gather; 16-byte aligned */
-    int32_t* error;           /* device out [1] */
+    int32_t* error;           /* device out [2]: the flag; the deepest root's level */
     int32_t N, T, V, null_id, start_id, scene_id;
+    int32_t spread;           /* 0: every node in its earliest level (1 + its deepest input's), the host
+                                 scheduler's levels without VQA_PLAN_BALANCE.  1: rows with slack run
+                                 some levels later, a different share of the slack per row, which evens
+                                 the launches out */
+    int32_t reserved;
 } vqa_devsched_params;
 
 int vqa_devsched_build(const vqa_devsched_params* p, void* stream);

@@ -32,11 +32,9 @@ for name, prog in sets.items():
     pt = torch.from_numpy(prog).to(dev)
     res = {}
     ref = None
-    for mode, (on_dev, balance, wgs) in (('host_balanced', (False, True, 0)), ('host', (False, False, 0)),
-                                         ('device_512', (True, False, 512)), ('device_1024', (True, False, 1024)),
-                                         ('device_2048', (True, False, 2048)), ('device_8192', (True, False, 8192))):
-        net.schedule_on_device, net.balance_levels = on_dev, balance
-        net.device_level_workgroups = wgs or 1024
+    for mode, (on_dev, balance) in (('host_balanced', (False, True)), ('host', (False, False)),
+                                    ('device', (True, False)), ('device_spread', (True, True))):
+        net.schedule_on_device, net.balance_levels, net.device_spread_levels = on_dev, balance, balance
         with torch.no_grad():
             for _ in range(3):
                 y = net(x, pt)

@@ -30,7 +30,7 @@ def quirk_rows(t2i, T):
             pad([N_] * (T - 1) + [S_]), pad([E_]), pad([un, eq, sc, sc, un, sc, fl, sc, E_]), [S_] * T, [fl] * T]
 
 
-def device_schedule(prog, vocab):
+def device_schedule(prog, vocab, spread=False):
     from vqa_amd import ops
     t2i = vocab['program_token_to_idx']
     arity = torch.tensor(V.arity_table(vocab), dtype=torch.int8).cuda()
@@ -39,29 +39,37 @@ def device_schedule(prog, vocab):
     buf = torch.full((ops.DeviceSchedule.words(N, T, nv),), -7, dtype=torch.int32, device='cuda')
     sched = ops.DeviceSchedule(buf, N, T, nv)
     used = torch.full((N, T), -1.0, device='cuda')
-    ops.devsched_build(torch.from_numpy(prog).cuda(), arity, used, sched, t2i['<NULL>'], t2i['<START>'], t2i['scene'])
+    ops.devsched_build(torch.from_numpy(prog).cuda(), arity, used, sched, t2i['<NULL>'], t2i['<START>'], t2i['scene'],
+                       spread=spread)
     torch.cuda.synchronize()
     return sched, used.cpu().numpy()
 
 
-def check_against_host(prog, vocab):
-    """Rebuild every row's tree from the device's tile records and compare with the host plan's."""
+def check_against_host(prog, vocab, spread=False):
+    """Rebuild every row's tree from the device's tile records and compare with the host plan's.
+    Levels: the host's earliest ones without `spread`; with it, any levels in which inputs run
+    before their users, no more of them than the deepest program needs."""
     scene = vocab['program_token_to_idx']['scene']
     N, T = prog.shape
-    sched, used = device_schedule(prog, vocab)
+    sched, used = device_schedule(prog, vocab, spread)
     plan = Plan(prog, vocab)
     nodes, roots = plan.nodes(), plan.roots()
     np.testing.assert_array_equal(used, plan.used_fns())
-    assert int(sched.error.item()) == 0
+    err = sched.error.cpu().numpy()
+    assert err[0] == 0 and err[1] == nodes[:, 5].max()
     li = sched.level_info.cpu().numpy().reshape(T + 1, 2)
     hist = sched.hist.cpu().numpy().reshape(T + 1, -1)
     want_hist = np.zeros_like(hist)
     for _s, tok, _c, _a, _b, lvl in nodes:
         if tok != scene:
             want_hist[lvl, tok] += 1
-    np.testing.assert_array_equal(hist, want_hist)
-    np.testing.assert_array_equal(li[:, 1], want_hist.sum(1))
-    np.testing.assert_array_equal(li[:, 0], np.concatenate([[0], np.cumsum(want_hist.sum(1))[:-1]]))
+    if spread:
+        np.testing.assert_array_equal(hist.sum(0), want_hist.sum(0))
+        assert hist[0].sum() == 0 and hist[err[1] + 1:].sum() == 0
+    else:
+        np.testing.assert_array_equal(hist, want_hist)
+    np.testing.assert_array_equal(li[:, 1], hist.sum(1))
+    np.testing.assert_array_equal(li[:, 0], np.concatenate([[0], np.cumsum(hist.sum(1))[:-1]]))
     total = int(li[:, 1].sum())
     tiles = sched.tiles.cpu().numpy().reshape(N * T, 12)[:total]
     assert (tiles[:, 5:7] == -1).all() and (tiles[:, 8:] == -1).all()
@@ -88,8 +96,11 @@ def check_against_host(prog, vocab):
             return (scene,), 0
         t = by_y[slot]
         kids = [dev_tree(int(s), row) for s in t[:2] if s >= 0]
-        lvl = 1 + max(k[1] for k in kids)
-        assert level_of[slot] == lvl
+        lvl = level_of[slot]
+        if spread:
+            assert lvl > max(k[1] for k in kids)
+        else:
+            assert lvl == 1 + max(k[1] for k in kids)
         return (int(t[7]),) + tuple(k[0] for k in kids), lvl
 
     def host_tree(v):
@@ -99,18 +110,22 @@ def check_against_host(prog, vocab):
     assert (cls[:, [1, 3, 4, 5, 6]] == -1).all() and (cls[:, 7] == 0).all()
     for i in range(N):
         assert dev_tree(int(cls[i, 0]), i)[0] == host_tree(roots[i]), i
+    return hist.sum(1), want_hist.sum(1)
 
 
-def test_wellformed_sampler_and_quirk_rows_give_the_host_schedule(vocab):
+@pytest.mark.parametrize('spread', [False, True])
+def test_wellformed_sampler_and_quirk_rows_give_the_host_schedule(vocab, spread):
     t2i = vocab['program_token_to_idx']
-    check_against_host(synth.synth_programs(1, 257, vocab), vocab)
-    check_against_host(synth.synth_sampler_programs(2, 300, len(t2i), 30), vocab)
-    check_against_host(synth.synth_sampler_programs(3, 64, len(t2i), 7), vocab)
-    check_against_host(synth.synth_programs(4, 32, vocab, max_len=64, max_nodes=60), vocab)
-    check_against_host(synth.synth_programs(5, 16, vocab, with_start=True), vocab)
-    check_against_host(np.array(quirk_rows(t2i, 14), dtype=np.int64), vocab)
-    check_against_host(np.array([[t2i['union']]], dtype=np.int64), vocab)          # T = 1
-    check_against_host(synth.synth_programs(6, 1500, vocab), vocab)                # more rows than one scan thread each
+    check_against_host(synth.synth_programs(1, 257, vocab), vocab, spread)
+    check_against_host(synth.synth_sampler_programs(2, 300, len(t2i), 30), vocab, spread)
+    check_against_host(synth.synth_sampler_programs(3, 64, len(t2i), 7), vocab, spread)
+    check_against_host(synth.synth_programs(4, 32, vocab, max_len=64, max_nodes=60), vocab, spread)
+    check_against_host(synth.synth_programs(5, 16, vocab, with_start=True), vocab, spread)
+    check_against_host(np.array(quirk_rows(t2i, 14), dtype=np.int64), vocab, spread)
+    check_against_host(np.array([[t2i['union']]], dtype=np.int64), vocab, spread)          # T = 1
+    got, earliest = check_against_host(synth.synth_programs(6, 1500, vocab), vocab, spread)   # more rows than one scan thread each
+    if spread:      # what it is for: the largest launch shrinks, the many small ones grow
+        assert got.max() < 0.6 * earliest.max() and (got[1:earliest.nonzero()[0].max()] >= 64).sum() > (earliest >= 64).sum()
 
 
 def test_token_outside_the_vocabulary_raises_the_flag(vocab):
@@ -120,7 +135,7 @@ def test_token_outside_the_vocabulary_raises_the_flag(vocab):
     prog[4, 0] = len(t2i)
     prog[6, 1] = -1
     sched, used = device_schedule(prog, vocab)
-    assert int(sched.error.item()) == 1
+    assert int(sched.error[0].item()) == 1
     assert (used[[4, 6]] == 0).all()
     # the other rows are scheduled as if the bad ones were lone scene modules
     good[[4, 6]] = t2i['<NULL>']
@@ -131,7 +146,7 @@ def test_token_outside_the_vocabulary_raises_the_flag(vocab):
     np.testing.assert_array_equal(li[:, 1], want)
 
 
-@pytest.mark.parametrize('balance', [False, True])
+@pytest.mark.parametrize('balance', [False, True])      # of the host's levels and of the device's
 def test_executor_gives_the_same_logits_with_the_schedule_made_on_the_device(vocab, balance):
     from vqa_amd.module_net import ModuleNet
     t2i = vocab['program_token_to_idx']
@@ -143,7 +158,7 @@ def test_executor_gives_the_same_logits_with_the_schedule_made_on_the_device(voc
     net = ModuleNet(False, vocab, **DIMS)
     net.load_state_dict(synth.synth_state_dict(13, vocab, **DIMS))
     net.cuda().eval()
-    net.balance_levels = balance
+    net.balance_levels = net.device_spread_levels = balance
     x = torch.from_numpy(synth.synth_features(14, n, DIMS['feature_dim'])).cuda()
     pt = torch.from_numpy(prog).cuda()
     with torch.no_grad():

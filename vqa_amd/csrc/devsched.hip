@@ -1,10 +1,10 @@
 // Program scheduler on the device (gfx950): the parse of forward_modules_ints_helper
-// (Module_Model.py:196-222) and the (level, token) bucketing of the whole batch as three small
+// (Module_Model.py:196-222) and the (level, token) bucketing of the whole batch as four small
 // kernels, so that programs a sampler left in device memory (LSTM_Model.py:205-235 builds them on
 // the GPU and copies them to the host every step, :228-235) become tile lists without a round
 // trip through the host.  Forward only (candidate scoring and evaluation: Train_model.py:339-354,
-// Functions.py:152-179); levels are the earliest ones (1 + the deepest input), which is what the
-// host scheduler produces without VQA_PLAN_BALANCE, so results are bit-identical to it.
+// Functions.py:152-179).  Which launch a node runs in does not change its value: results are
+// bit-identical to the host scheduler's, with or without either side's level balancing.
 //
 // The host never learns the node counts: the arena uses fixed strides (a row has at most T nodes
 // that are not the scene module), the launch of a level has a fixed number of workgroups which
@@ -114,15 +114,41 @@ __global__ __launch_bounds__(64) void devsched_parse_kernel(vqa_devsched_params 
             if ((w0 & 255) == p.scene_id) continue;
             nv++;
             nb += c1 >= 0;
-            atomicAdd(p.hist + (w0 >> 8) * p.V + (w0 & 255), 1);
         }
-        *((int4*)p.counts + row) = make_int4(n, nv, nb, root);
+        const int root_level = node[root * 4 * B + t] >> 8;
+        atomicMax(p.error + 1, root_level);
+        *((int4*)p.counts + row) = make_int4(n, nv, nb, root | root_level << 16);
     }
     __syncthreads();
     for (int idx = t; idx < B * T; idx += B) {
         const int r = idx / T, j = idx - r * T;
         if (row0 + r < p.N) p.used[(int64_t)(row0 + r) * T + j] = (toks[j * B + r] & USED_BIT) ? 1.f : 0.f;
     }
+}
+
+// The level a node runs in.  Its earliest one is 1 + the deepest input's; with `spread`, a row whose
+// root sits below the batch's deepest root runs as a whole some levels later, by a share of its
+// slack that differs from row to row (a van der Corput sequence over the row number): the earliest
+// levels alone make the first launches huge and the last dozen tiny, and every launch, however
+// small, costs a tile's latency.  Inputs still run before their users, results do not change.
+__device__ __forceinline__ int final_level(const vqa_devsched_params& p, int row, int root_level, int earliest) {
+    if (!p.spread) return earliest;
+    const int slack = p.error[1] - root_level;
+    const float u = (float)__brev((unsigned)(row + 1)) * 2.3283064365386963e-10f;      // [0, 1)
+    return earliest + min(slack, (int)(u * (float)(slack + 1)));
+}
+
+// One thread per (row, node): the (level, token) histogram of the nodes that are not the scene module.
+__global__ __launch_bounds__(256) void devsched_hist_kernel(vqa_devsched_params p) {
+    const int R = 2 * p.T + 1;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)p.N * R) return;
+    const int row = (int)(gid / R), k = (int)(gid - (int64_t)row * R);
+    const int4 cnt = *((const int4*)p.counts + row);
+    if (k >= cnt.x) return;
+    const int w0 = ((const int4*)p.node + (int64_t)row * R + k)->x;
+    if ((w0 & 255) == p.scene_id) return;
+    atomicAdd(p.hist + final_level(p, row, cnt.w >> 16, w0 >> 8) * p.V + (w0 & 255), 1);
 }
 
 // exclusive scan of one value per thread over the workgroup (1024 threads)
@@ -197,11 +223,11 @@ __global__ __launch_bounds__(256) void devsched_emit_kernel(vqa_devsched_params 
     const int4* nodes = (const int4*)p.node + (int64_t)row * R;
     const int4 nd = nodes[k];
     const int N = p.N, nvmax = p.N * p.T;
-    const int tok = nd.x & 255, L = nd.x >> 8;
+    const int tok = nd.x & 255, L = final_level(p, row, cnt.w >> 16, nd.x >> 8);
     const int vbase = p.row_base[row * 2], bbase = p.row_base[row * 2 + 1];
     const bool scene = tok == p.scene_id;
     const int y = scene ? 2 * N + row : 4 * N + vbase + (nd.w & 0xffff);
-    if (k == cnt.w) {
+    if (k == (cnt.w & 0xffff)) {
         // the classifier's gather: root map of the row -> row of the classifier input (the torch.cat
         // of Module_Model.py:232)
         int4* ct = (int4*)p.cls_tiles + (int64_t)row * 2;
@@ -251,11 +277,12 @@ extern "C" int vqa_devsched_build(const vqa_devsched_params* p, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(p->hist, 0, (size_t)(p->T + 1) * p->V * sizeof(int32_t), s);
-    if (e == hipSuccess) e = hipMemsetAsync(p->error, 0, sizeof(int32_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(p->error, 0, 2 * sizeof(int32_t), s);
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_devsched_build: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     hipLaunchKernelGGL(devsched_parse_kernel, dim3((p->N + rows - 1) / rows), dim3(rows), rows * per_row + fixed, s, *p);
-    hipLaunchKernelGGL(devsched_scan_kernel, dim3(1), dim3(1024), scan_lds, s, *p);
     const int64_t threads = (int64_t)p->N * (2 * p->T + 1);
+    hipLaunchKernelGGL(devsched_hist_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(devsched_scan_kernel, dim3(1), dim3(1024), scan_lds, s, *p);
     hipLaunchKernelGGL(devsched_emit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, *p);
     e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_devsched_build: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }

@@ -252,6 +252,7 @@ class ModuleNet(nn.Module):
         # token id outside the vocabulary cannot raise from an asynchronous launch: it sets
         # schedule_error (see raise_for_schedule_error)
         self.schedule_on_device = False
+        self.device_spread_levels = True     # rows with slack run later by differing shares of it: evener launches
         self.device_level_workgroups = 512     # two per CU: all resident at once
         self.schedule_error = None
         self._arity_dev = None
@@ -607,7 +608,8 @@ class ModuleNet(nn.Module):
                 sched, used = self._device_schedule_buffers(ws, N, T, dev)
                 t2i = self.vocab['program_token_to_idx']
                 with torch.cuda.stream(side):
-                    ops.devsched_build(prog_dev, self._arity_dev, used, sched, t2i['<NULL>'], t2i['<START>'], t2i['scene'])
+                    ops.devsched_build(prog_dev, self._arity_dev, used, sched, t2i['<NULL>'], t2i['<START>'], t2i['scene'],
+                                       spread=self.device_spread_levels)
                     sched_done = torch.cuda.Event()
                     sched_done.record(side)
                 prog_dev.record_stream(side)
@@ -686,7 +688,7 @@ class ModuleNet(nn.Module):
                 cur.wait_event(sched_done)
                 # Module_Model.py:227,231: a float tensor on the program's device
                 self.used_fns = used
-                self.schedule_error = sched.error.clone()      # the workspace is reused by later calls
+                self.schedule_error = sched.error[:1].clone()      # the workspace is reused by later calls
                 self.last_token_counts = None
                 st['plan'] = plan = None
                 st['arena'] = arena_full[:dev_slots * HW * c]

@@ -93,12 +93,12 @@ class DeviceSchedule:
         self.N, self.T, self.V = N, T, V
         self.tiles, self.cls_tiles = take(N * T * 12), take(N * 8)
         self.level_info, self.hist = take((T + 1) * 2), take((T + 1) * V)
-        self.error = take(1)
+        self.error = take(2)          # the flag; the deepest root's level
         self.node, self.counts = take(N * (2 * T + 1) * 4), take(N * 4)
         self.row_base, self.bin_off, self.bin_cursor = take(N * 2), take((T + 1) * V), take((T + 1) * V)
 
 
-def devsched_build(programs, arity, used, sched, null_id, start_id, scene_id):
+def devsched_build(programs, arity, used, sched, null_id, start_id, scene_id, spread=False):
     """Programs in device memory -> tile lists in device memory (vqa_devsched_build): `programs`
     int64 [N][T], `arity` int8 [V], `used` float32 [N][T] out, `sched` a DeviceSchedule."""
     _need_cuda(programs, arity, used, sched.tiles)
@@ -112,6 +112,7 @@ def devsched_build(programs, arity, used, sched, null_id, start_id, scene_id):
               'cls_tiles', 'error'):
         setattr(p, k, getattr(sched, k).data_ptr())
     p.N, p.T, p.V, p.null_id, p.start_id, p.scene_id = N, T, sched.V, null_id, start_id, scene_id
+    p.spread = int(spread)
     _lib.check(_lib.load().vqa_devsched_build(C.byref(p), _stream()))
 
 
