@@ -187,3 +187,16 @@ def test_executor_gives_the_same_logits_with_the_schedule_made_on_the_device(voc
         net(x, bad)
     with pytest.raises(KeyError):
         net.raise_for_schedule_error()
+
+
+def test_sizes_beyond_the_limits_are_refused(vocab):
+    """Programs too long for the scan's LDS histogram, or for the packed node records, raise with
+    a message instead of launching; one row of one token works."""
+    from vqa_amd import _lib
+    t2i = vocab['program_token_to_idx']
+    for T, msg in ((400, 'too long'), (1100, 'bad argument')):
+        with pytest.raises(_lib.VqaError, match=msg):
+            device_schedule(np.full((2, T), t2i['scene'], dtype=np.int64), vocab)
+    sched, used = device_schedule(np.array([[t2i['scene']]], dtype=np.int64), vocab)
+    assert used.tolist() == [[1.0]] and sched.level_info.cpu().numpy()[:, ].reshape(-1, 2)[:, 1].sum() == 0
+    assert sched.cls_tiles.cpu().numpy()[0] == 2          # the scene output of image 0 (slot 2N + 0)

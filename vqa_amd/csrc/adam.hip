@@ -231,10 +231,7 @@ extern "C" int vqa_adam_conv_pack(const vqa_adam_conv_tensor* tensors, int32_t n
     }
     if (num_tensors == 0) return VQA_OK;
     const int lds = (cin * taps + 8) * 8 * 2;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)adam_conv_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { vqa_set_error(std::string("vqa_adam_conv_pack: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
-    }
+    if (lds > 64 * 1024 && !vqa_allow_lds((const void*)adam_conv_pack_kernel, 160 * 1024, "vqa_adam_conv_pack")) return VQA_ELAUNCH;
     hipLaunchKernelGGL(adam_conv_pack_kernel, dim3(cout / 8, num_tensors), dim3(256), lds, (hipStream_t)stream, tensors,
                        cout, cin, taps, weight_decay, beta1, beta2, eps);
     hipError_t e = hipGetLastError();

@@ -463,12 +463,8 @@ extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stre
         return VQA_EINVAL;
     }
     if (p->num_tiles == 0) return VQA_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_tiles_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_tiles_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
-        attr_set = true;
-    }
+    if (!vqa_allow_lds((const void*)conv_tiles_kernel<9>, CONV_LDS, "vqa_conv_tiles") ||
+        !vqa_allow_lds((const void*)conv_tiles_kernel<1>, CONV_LDS, "vqa_conv_tiles")) return VQA_ELAUNCH;
     dim3 grid(p->num_tiles, p->n_out / 128), block(256);
     const double kdim = (double)p->k_chunks * 128 * taps;
     VqaProfScope prof(taps == 9 ? VQA_K_CONV9 : VQA_K_CONV1, 2.0 * VQA_HW * kdim * p->n_out * p->num_tiles,
@@ -489,12 +485,8 @@ extern "C" int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream) {
         return VQA_EINVAL;
     }
     if (p->num_tiles == 0) return VQA_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)resblock_tiles_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
-        (void)hipFuncSetAttribute((const void*)resblock_tiles_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
-        attr_set = true;
-    }
+    if (!vqa_allow_lds((const void*)resblock_tiles_kernel<false>, CONV_LDS, "vqa_resblock_tiles") ||
+        !vqa_allow_lds((const void*)resblock_tiles_kernel<true>, CONV_LDS, "vqa_resblock_tiles")) return VQA_ELAUNCH;
     // two 3x3 convolutions of 128 -> 128 channels per tile, plus the 1x1 projection of binary nodes
     VqaProfScope prof(VQA_K_RESBLOCK, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles +
                                           2.0 * VQA_HW * 256.0 * 128.0 * (p->num_pre + p->num_post),

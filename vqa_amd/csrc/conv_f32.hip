@@ -222,12 +222,8 @@ extern "C" int vqa_wgrad_tiles_f32(const vqa_wgrad_params* p, int32_t taps, void
         return VQA_EINVAL;
     }
     if (p->num_items == 0) return VQA_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tiles_f32_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, F32_WG_LDS);
-        (void)hipFuncSetAttribute((const void*)wgrad_tiles_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F32_WG_LDS);
-        attr_set = true;
-    }
+    if (!vqa_allow_lds((const void*)wgrad_tiles_f32_kernel<9>, F32_WG_LDS, "vqa_wgrad_tiles_f32") ||
+        !vqa_allow_lds((const void*)wgrad_tiles_f32_kernel<1>, F32_WG_LDS, "vqa_wgrad_tiles_f32")) return VQA_ELAUNCH;
     dim3 grid(p->num_items, p->n_out / 64, p->k_chunks * 4), block(256);
     if (taps == 9) hipLaunchKernelGGL(wgrad_tiles_f32_kernel<9>, grid, block, F32_WG_LDS, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(wgrad_tiles_f32_kernel<1>, grid, block, F32_WG_LDS, (hipStream_t)stream, *p);

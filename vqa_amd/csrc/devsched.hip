@@ -269,12 +269,8 @@ extern "C" int vqa_devsched_build(const vqa_devsched_params* p, void* stream) {
         vqa_set_error("vqa_devsched_build: programs too long for the device scheduler");
         return VQA_EINVAL;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)devsched_parse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        (void)hipFuncSetAttribute((const void*)devsched_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
-        attr_set = true;
-    }
+    if (!vqa_allow_lds((const void*)devsched_parse_kernel, 144 * 1024, "vqa_devsched_build") ||
+        !vqa_allow_lds((const void*)devsched_scan_kernel, 60 * 1024, "vqa_devsched_build")) return VQA_ELAUNCH;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(p->hist, 0, (size_t)(p->T + 1) * p->V * sizeof(int32_t), s);
     if (e == hipSuccess) e = hipMemsetAsync(p->error, 0, 2 * sizeof(int32_t), s);

@@ -343,28 +343,20 @@ extern "C" int vqa_gemm(const vqa_gemm_params* p, void* stream) {
         vqa_set_error("vqa_gemm: bad argument (K must be a multiple of 64, leading dimensions of 8; 4 for an fp32 result)");
         return VQA_EINVAL;
     }
-    static bool attr_set = false;
     constexpr int ST = GT_STAGES;
     const int lds = ST * 2 * GT_BYTES > 128 * GT_STAGE_LD * 4 ? ST * 2 * GT_BYTES : 128 * GT_STAGE_LD * 4;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<false, true, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<true, false, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    if (!vqa_allow_lds((const void*)gemm_kernel<false, false, ST>, lds, "vqa_gemm") ||
+        !vqa_allow_lds((const void*)gemm_kernel<false, true, ST>, lds, "vqa_gemm") ||
+        !vqa_allow_lds((const void*)gemm_kernel<true, true, ST>, lds, "vqa_gemm") ||
+        !vqa_allow_lds((const void*)gemm_kernel<true, false, ST>, lds, "vqa_gemm")) return VQA_ELAUNCH;
     hipStream_t s = (hipStream_t)stream;
     if (p->M % 256 == 0 && p->N % 256 == 0 && (int64_t)(p->M / 256) * (p->N / 256) * p->split_k >= 128) {
         // large problems: 256 x 256 tiles
-        static bool attr256_set = false;
         const int lds256 = 128 * GB_STAGE_LD * 4 > 8 * GT_BYTES ? 128 * GB_STAGE_LD * 4 : 8 * GT_BYTES;
-        if (!attr256_set) {
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-            attr256_set = true;
-        }
+        if (!vqa_allow_lds((const void*)gemm256_kernel<false, false>, lds256, "vqa_gemm") ||
+            !vqa_allow_lds((const void*)gemm256_kernel<false, true>, lds256, "vqa_gemm") ||
+            !vqa_allow_lds((const void*)gemm256_kernel<true, true>, lds256, "vqa_gemm") ||
+            !vqa_allow_lds((const void*)gemm256_kernel<true, false>, lds256, "vqa_gemm")) return VQA_ELAUNCH;
         const int tm = p->M / 256, tn = p->N / 256;
         const int gm = tm < 4 ? tm : 4, gn = tn < 32 / gm ? tn : 32 / gm;
         const int64_t groups = (int64_t)((tm + gm - 1) / gm) * ((tn + gn - 1) / gn) * p->split_k;

@@ -4,6 +4,7 @@
 #include "plan.h"
 
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -62,4 +63,22 @@ extern "C" int vqa_prof_collect(double* out, int32_t kinds) {
     }
     g_recs.clear();
     return VQA_OK;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per (kernel, device).  A kernel's code object
+// is loaded per device, so the limit is raised on each device the library is used on.
+bool vqa_allow_lds(const void* kernel, int bytes, const char* who) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const auto& d : done)
+            if (d.first == kernel && d.second == dev) return true;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) { done.emplace_back(kernel, dev); return true; }
+    }
+    vqa_set_error(std::string(who) + ": raising the dynamic LDS limit: " + hipGetErrorString(e));
+    return false;
 }

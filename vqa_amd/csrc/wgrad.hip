@@ -233,12 +233,8 @@ extern "C" int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* st
         return VQA_EINVAL;
     }
     if (p->num_items == 0) return VQA_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tiles_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS);
-        (void)hipFuncSetAttribute((const void*)wgrad_tiles_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS);
-        attr_set = true;
-    }
+    if (!vqa_allow_lds((const void*)wgrad_tiles_kernel<9>, WGRAD_LDS, "vqa_wgrad_tiles") ||
+        !vqa_allow_lds((const void*)wgrad_tiles_kernel<1>, WGRAD_LDS, "vqa_wgrad_tiles")) return VQA_ELAUNCH;
     const int64_t blocks = (int64_t)((p->num_items + 7) / 8) * 8 * (p->n_out / 64) * (p->k_chunks * 2);
     if (blocks > 0x7fffffff) { vqa_set_error("vqa_wgrad_tiles: too many work items"); return VQA_EINVAL; }
     dim3 grid((unsigned)blocks), block(256);
