@@ -285,7 +285,9 @@ int vqa_pack_conv_weight(const float* w, void* packed, int32_t groups, int32_t n
  * (Train_model.py:313 over Module_Model.py:221).  Two ways out for dW: fp32 atomics into `dw`
  * (zero it first), or, when `partial` is set, one block of taps * 8192 floats per workgroup
  * (num_items * n_out/64 * k_chunks blocks), which vqa_wgrad_reduce sums per group into torch's
- * layout; the second is several times cheaper and deterministic.  db is always atomic.
+ * layout; the second is several times cheaper and deterministic.  db likewise: fp32 atomics, or,
+ * in partial-block mode with `bias_block` set, one row of n_out sums per item that
+ * vqa_wgrad_reduce adds per group in item order (the same bits on every run).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t group;   /* weight group (token id) */
@@ -312,7 +314,11 @@ typedef struct {
     int32_t n_out;              /* channels of dy (o), multiple of 64 */
     int32_t num_items;
     int32_t total_nodes;        /* sum of the items' counts (work accounting only) */
-    int32_t reserved;
+    int32_t bias_block;         /* 0: the bias sums are added to db with atomics.  > 0 (partial-block
+                                   mode): they are stored, [item][n_out], at partial + bias_block *
+                                   8192 floats - behind the num_items * n_out/64 * k_chunks * taps
+                                   blocks of the launch - and db is not touched; vqa_wgrad_reduce
+                                   sums them */
 } vqa_wgrad_params;
 
 int vqa_wgrad_tiles(const vqa_wgrad_params* p, int32_t taps, void* stream);
@@ -320,10 +326,12 @@ int vqa_wgrad_tiles_f32(const vqa_wgrad_params* p, int32_t taps, void* stream);
 
 /* out[group][n][k][tap] (torch's OIHW, groups apart by out_g_stride) = sum of the partial blocks
  * of the group's items; a group without items gets zeros.  items / num_items / n_out / k_chunks as
- * in the vqa_wgrad_tiles call that wrote `partial`. */
+ * in the vqa_wgrad_tiles call that wrote `partial`.  bias_partial / db: null, or the [item][n_out]
+ * sums that call stored (its partial + bias_block * 8192) and the fp32 [groups][n_out] array that
+ * receives their per-group sums (written whole; n_out <= 512). */
 int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* items, int32_t num_items,
                      int32_t groups, int32_t n_out, int32_t k_chunks, int32_t taps, float* out,
-                     int64_t out_g_stride, void* stream);
+                     int64_t out_g_stride, const float* bias_partial, float* db, void* stream);
 
 /* vqa_wgrad_tiles in partial-block mode followed by vqa_wgrad_reduce, for callers that cannot
  * allocate device memory or bring a workspace: code under HIP graph capture, tight serving loops,

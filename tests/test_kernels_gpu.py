@@ -305,6 +305,21 @@ def test_wgrad3x3_grouped_accumulates_over_nodes():
     assert torch.equal(outs[0], outs[1])
     close(outs[0], out, 1e-5)
     assert outs[0][1].abs().max() == 0
+    # the bias sums as per-item rows behind the partial blocks, added per group by the reduction:
+    # the atomics' sums, group 1 written as zeros, db untouched by the first launch
+    part = torch.full((sum(ops.wgrad_blocks(3, C, 1, 9)) * 8192,), float('nan'), device=dev())
+    db2 = torch.full((G, C), 7.0, device=dev())
+    ops.wgrad_tiles(arena, arena, (items, 0), 3, (src_slots, 0), (dy_slots, 0), None, db2, taps=9, k_chunks=1,
+                    n_out=C, src_slot_stride=HW * C, dy_slot_stride=HW * C, src_pix_stride=C,
+                    dy_pix_stride=C, dw_group_stride=9 * C * C, partial=part, bias_rows=True)
+    torch.cuda.synchronize()
+    assert (db2 == 7.0).all()
+    o3 = torch.empty(G, C, C, 3, 3, device=dev())
+    ops.wgrad_reduce(part, (items, 0), 3, G, C, 1, 9, o3, C * C * 9, db=db2)
+    torch.cuda.synchronize()
+    assert torch.equal(o3.cpu(), outs[0])
+    close(db2.cpu(), db, 1e-5)
+    assert db2[1].abs().max() == 0
 
 
 def test_wgrad1x1_pair_sources():

@@ -34,7 +34,7 @@ class WgradParams(C.Structure):
                 ('dy_slots', vp), ('dw', vp), ('db', vp), ('partial', vp), ('src_slot_stride', i64),
                 ('dy_slot_stride', i64), ('dw_group_stride', i64), ('src_pix_stride', i32),
                 ('dy_pix_stride', i32), ('k_chunks', i32), ('pair_chunks', i32), ('n_out', i32),
-                ('num_items', i32), ('total_nodes', i32), ('reserved', i32)]
+                ('num_items', i32), ('total_nodes', i32), ('bias_block', i32)]
 
 
 class GemmParams(C.Structure):
@@ -105,7 +105,7 @@ SIGNATURES = {
     'vqa_slot_sum_mask_f32': (i32, [vp, vp, vp, vp, vp, i32, i64, vp]),
     'vqa_pack_conv_weight': (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp]),
     'vqa_wgrad_tiles': (i32, [C.POINTER(WgradParams), i32, vp]),
-    'vqa_wgrad_reduce': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
+    'vqa_wgrad_reduce': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp]),
     'vqa_wgrad_tiles_noalloc': (i32, [C.POINTER(WgradParams), i32, i32, vp, i64, vp]),
     'vqa_unpack_conv_grad': (i32, [vp, vp, i32, i32, i32, i32, i64, vp]),
     'vqa_gemm': (i32, [C.POINTER(GemmParams), vp]),

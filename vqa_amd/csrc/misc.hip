@@ -227,26 +227,31 @@ extern "C" int vqa_bias_act(const float* acc, const float* bias, void* out, int3
     return VQA_OK;
 }
 
-// out[col] += sum_rows x[row][col]; block = 64 columns x 4 row lanes, grid.y splits the rows
-__global__ __launch_bounds__(256) void col_sum_kernel(const void* __restrict__ x, float* __restrict__ out, int rows,
-                                                      int cols, int64_t ld, int is_bf16) {
-    __shared__ float red[256];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+// out[col] += sum_rows x[row][col]; block = 32 columns x 32 row lanes, one block per column range:
+// the sum of a column is formed in one fixed order (no atomics), the same bits on every run
+__global__ __launch_bounds__(1024) void col_sum_kernel(const void* __restrict__ x, float* __restrict__ out, int rows,
+                                                       int cols, int64_t ld, int is_bf16) {
+    __shared__ float red[1024];
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;
     float s = 0.f;
     if (col < cols)
-        for (int r = blockIdx.y * 4 + part; r < rows; r += gridDim.y * 4)
+        for (int r = part; r < rows; r += 32)
             s += is_bf16 ? bf2f(((const bf16_t*)x)[r * ld + col]) : ((const float*)x)[r * ld + col];
     red[threadIdx.x] = s;
     __syncthreads();
-    if (part == 0 && col < cols)
-        atomicAdd(out + col, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    if (part == 0 && col < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; k++) t += red[threadIdx.x + 32 * k];
+        out[col] += t;
+    }
 }
 
 extern "C" int vqa_col_sum(const void* x, float* out, int32_t rows, int32_t cols, int64_t ld, int32_t is_bf16,
                            void* stream) {
     if (!x || !out || rows <= 0 || cols <= 0) { vqa_set_error("vqa_col_sum: bad argument"); return VQA_EINVAL; }
-    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, std::min(32, (rows + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, out, rows, cols, ld, is_bf16);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 31) / 32), dim3(1024), 0, (hipStream_t)stream, x, out, rows, cols, ld,
+                       is_bf16);
     CHECK_LAUNCH("vqa_col_sum");
     return VQA_OK;
 }

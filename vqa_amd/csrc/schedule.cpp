@@ -625,10 +625,12 @@ extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
     o->num_exec_nodes = pl->num_exec;
     o->blob_fwd_words = pl->fwd_words;
     o->blob_words_bound = (int)pl->blob_bound;
-    {   // one block of 8192 floats per tap and workgroup of the largest weight-gradient launch
+    {   // one block of 8192 floats per tap and workgroup of the largest weight-gradient launch, and
+        // behind them one row of C bias sums per item
         const int cc = pl->C / 128, os = pl->C / 64;
-        o->wgrad_partial_blocks = std::max(pl->sec_cnt[VQA_SEC_WG_ITEMS] * os * cc * 9,
-                                           pl->sec_cnt[VQA_SEC_WG_PITEMS] * os * 2 * cc);
+        const int it = pl->sec_cnt[VQA_SEC_WG_ITEMS], pit = pl->sec_cnt[VQA_SEC_WG_PITEMS];
+        auto rows = [&](int items) { return (int)(((int64_t)items * pl->C + 8191) / 8192); };
+        o->wgrad_partial_blocks = std::max(it * os * cc * 9 + rows(it), pit * os * 2 * cc + rows(pit));
     }
     return VQA_OK;
 }

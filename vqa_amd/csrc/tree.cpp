@@ -186,17 +186,19 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
         }
         return VQA_OK;
     }
+    // partial blocks, and behind them one row of bias sums per item: both summed per token by
+    // vqa_wgrad_reduce in item order, so every gradient comes out the same on every run
     w.partial = c->wgrad_partial;
+    w.bias_block = w.num_items * (pl->C / 64) * cc * 9;
+    const float* bias_rows = w.partial + (int64_t)w.bias_block * 8192;
     w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C1];
     w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C1];
-    w.db = c->gb_conv1;
     if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
-    if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv1, w33, stream))) return rc;
+    if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv1, w33, bias_rows, c->gb_conv1, stream))) return rc;
     w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C2];
     w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C2];
-    w.db = c->gb_conv2;
     if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
-    if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv2, w33, stream))) return rc;
+    if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv2, w33, bias_rows, c->gb_conv2, stream))) return rc;
     if (pl->sec_cnt[VQA_SEC_WG_PITEMS] > 0) {
         w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_PITEMS]);
         w.num_items = pl->sec_cnt[VQA_SEC_WG_PITEMS];
@@ -205,11 +207,13 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
         w.src1_slots = c->blob + pl->sec_off[VQA_SEC_WG_PSRC1];
         w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_PDY];
         w.k_chunks = 2 * cc; w.pair_chunks = cc;
-        w.db = c->gb_proj;
+        w.bias_block = w.num_items * (pl->C / 64) * 2 * cc;
+        bias_rows = w.partial + (int64_t)w.bias_block * 8192;
         if ((rc = vqa_wgrad_tiles(&w, 1, stream))) return rc;
-        if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, 2 * cc, 1, c->g_proj, w11, stream))) return rc;
+        if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, 2 * cc, 1, c->g_proj, w11, bias_rows, c->gb_proj, stream))) return rc;
     } else if (c->g_proj) {
         hipError_t e = hipMemsetAsync(c->g_proj, 0, (size_t)c->V * w11 * sizeof(float), (hipStream_t)stream);
+        if (e == hipSuccess && c->gb_proj) e = hipMemsetAsync(c->gb_proj, 0, (size_t)c->V * pl->C * sizeof(float), (hipStream_t)stream);
         if (e != hipSuccess) { vqa_set_error("vqa_tree_backward: memset failed"); return VQA_ELAUNCH; }
     }
     return VQA_OK;

@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
                 }
     }
 
-    if (p.db && kchunk == 0 && khalf == 0) {
+    const bool bias_rows = p.partial && p.bias_block > 0;
+    if ((p.db || bias_rows) && kchunk == 0 && khalf == 0) {
         __syncthreads();
         float* red = (float*)smem;       // [256][8]
 #pragma unroll
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
             const int pc = tid >> 3, j = tid & 7;
             float s = 0.f;
             for (int u = pc; u < 256; u += 8) s += red[u * 8 + j];
-            atomicAdd(p.db + (int64_t)it.group * p.n_out + oslice * 64 + tid, s);
+            if (bias_rows) p.partial[(int64_t)p.bias_block * 8192 + (int64_t)item * p.n_out + oslice * 64 + tid] = s;
+            else atomicAdd(p.db + (int64_t)it.group * p.n_out + oslice * 64 + tid, s);
         }
     }
 }
@@ -261,7 +263,8 @@ template <int TAPS, int U, int SEG>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const vqa_wgrad_item* __restrict__ items, int num_items,
                                                            int n_out, int k_chunks, float* __restrict__ out,
-                                                           int64_t out_g_stride) {
+                                                           int64_t out_g_stride, const float* __restrict__ bias_partial,
+                                                           float* __restrict__ db) {
     typedef float f32x4r __attribute__((ext_vector_type(4)));
     constexpr int COLS = 256 / SEG;
     __shared__ int list[256];
@@ -279,6 +282,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     f32x4r acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; t++) acc[t] = (f32x4r){0.f, 0.f, 0.f, 0.f};
+    // the group's bias sums: one more workgroup per group, next to the ones that sum weight blocks
+    // (inside one of those it would be the launch's tail); thread = output channel (two of them when
+    // n_out > 256), the items' rows added in list order
+    const bool do_bias = db != nullptr && blockIdx.x == gridDim.x - 1;
+    float bacc[2] = {0.f, 0.f};
     for (int base = 0; base < num_items; base += 256) {
         const int j = base + tid;
         const bool mine = j < num_items && items[j].group == grp;
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int w = 0; w < 4; w++) { if (w < wave) off += wcount[w]; n += wcount[w]; }
         if (mine) list[off + __popcll(b & ((1ull << lane) - 1))] = j;
         __syncthreads();
-        for (int k = seg * U; k < n; k += SEG * U) {
+        for (int k = seg * U; k < n && !do_bias; k += SEG * U) {
             f32x4r v[U][TAPS];
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -306,7 +314,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                     for (int t = 0; t < TAPS; t++) acc[t] += v[u][t];
                 }
         }
+        if (do_bias) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int o = tid + 256 * h;
+                if (o < n_out)
+                    for (int k = 0; k < n; k += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = k + u < n ? bias_partial[(int64_t)list[k + u] * n_out + o] : 0.f;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) bacc[h] += v[u];
+                    }
+            }
+        }
         __syncthreads();       // the list is rewritten by the next window
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            if (tid + 256 * h < n_out) db[(int64_t)grp * n_out + tid + 256 * h] = bacc[h];
+        return;
     }
     if (SEG > 1) {
         if (seg > 0) {
@@ -333,9 +361,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 extern "C" int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* items, int32_t num_items,
                                 int32_t groups, int32_t n_out, int32_t k_chunks, int32_t taps, float* out,
-                                int64_t out_g_stride, void* stream) {
+                                int64_t out_g_stride, const float* bias_partial, float* db, void* stream) {
     if (!partial || !items || !out || num_items < 0 || groups <= 0 || n_out <= 0 || n_out % 64 != 0 ||
-        k_chunks <= 0 || (taps != 9 && taps != 1)) {
+        k_chunks <= 0 || (taps != 9 && taps != 1) || ((db != nullptr) != (bias_partial != nullptr)) ||
+        (db && n_out > 512)) {
         vqa_set_error("vqa_wgrad_reduce: bad argument");
         return VQA_EINVAL;
     }
@@ -343,13 +372,14 @@ extern "C" int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* item
     dim3 block(256);
     hipStream_t s = (hipStream_t)stream;
     // (single-tap blocks are small: there the plain form is as fast, measured)
+    const int extra = db ? 1 : 0;                                  // the bias workgroup of each group
     if (taps == 1 || (int64_t)(cols4 / 256) * groups >= 512) {
-        dim3 grid(cols4 / 256, groups);
-        if (taps == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<9, 3, 1>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride);
-        else hipLaunchKernelGGL((wgrad_reduce_kernel<1, 8, 1>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride);
+        dim3 grid(cols4 / 256 + extra, groups);
+        if (taps == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<9, 3, 1>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride, bias_partial, db);
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<1, 8, 1>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride, bias_partial, db);
     } else {
-        dim3 grid(cols4 / 32, groups);
-        hipLaunchKernelGGL((wgrad_reduce_kernel<9, 2, 8>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride);
+        dim3 grid(cols4 / 32 + extra, groups);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<9, 2, 8>), grid, block, 0, s, partial, items, num_items, n_out, k_chunks, out, out_g_stride, bias_partial, db);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_wgrad_reduce: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
@@ -410,8 +440,9 @@ extern "C" int vqa_wgrad_tiles_noalloc(const vqa_wgrad_params* p, int32_t taps, 
     vqa_wgrad_params q = *p;
     q.partial = sc;          // every block the reduction reads is written whole by this launch: nothing to clear
     q.dw = nullptr;
+    q.bias_block = 0;        // db by atomics: the scratch holds weight-gradient blocks only
     if ((rc = vqa_wgrad_tiles(&q, taps, stream))) return rc;
-    return vqa_wgrad_reduce(sc, q.items, q.num_items, groups, q.n_out, q.k_chunks, taps, out, out_g_stride, stream);
+    return vqa_wgrad_reduce(sc, q.items, q.num_items, groups, q.n_out, q.k_chunks, taps, out, out_g_stride, nullptr, nullptr, stream);
 }
 
 // dW accumulators [group][tap][k][n] fp32 -> torch's [n][k][tap] per group

@@ -1204,15 +1204,18 @@ class ModuleNet(nn.Module):
         sec = lambda n: (blob, plan.section(n)[0])
         gcb = torch.zeros(p_, **f32)
         info = plan.info
-        need_blocks = max(info.wgrad_partial_blocks, it_cnt * (p_ // 64) * (c // 128),
-                          it_cnt * (c // 64) * (cpad // 128) * 9,
-                          plan.section('SAMPLE_ITEMS_FINE')[1] * (c // 64) * (c // 128) * 9)
+        # partial blocks of the largest launch, with one row of bias sums per item behind them: every
+        # gradient is summed in item order, the same bits on every run
+        need_blocks = max(info.wgrad_partial_blocks, sum(ops.wgrad_blocks(it_cnt, p_, c // 128, 1)),
+                          sum(ops.wgrad_blocks(it_cnt, c, cpad // 128, 9)),
+                          sum(ops.wgrad_blocks(plan.section('SAMPLE_ITEMS_FINE')[1], c, c // 128, 9)))
         part = ws.get('wg_partial', need_blocks * 8192, torch.float32, dev)
         ops.wgrad_tiles(arena, dc1, (blob, it_off), it_cnt, sec('SLOTS_ROOTY'), sec('SLOTS_IDENT'), None, gcb,
                         taps=1, k_chunks=c // 128, n_out=p_, src_slot_stride=HW * c, dy_slot_stride=HW * p_,
-                        src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_, total_nodes=N, partial=part)
+                        src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_, total_nodes=N, partial=part,
+                        bias_rows=True)
         gw = torch.empty(p_, c, 1, 1, **f32)
-        ops.wgrad_reduce(part, (blob, it_off), it_cnt, 1, p_, c // 128, 1, gw, 0)
+        ops.wgrad_reduce(part, (blob, it_off), it_cnt, 1, p_, c // 128, 1, gw, 0, db=gcb)
         grads['classifier.0.weight'], grads['classifier.0.bias'] = gw, gcb
         self._conv(st, dc1, arena, pk['wd_cls'], 'CLS_DGRAD_TILES', 1, p_ // 128, c, (HW * p_, p_), slot,
                    mask=arena)
@@ -1253,16 +1256,18 @@ class ModuleNet(nn.Module):
         fi_off, fi_cnt = plan.section('SAMPLE_ITEMS_FINE')
         ops.wgrad_tiles(arena, arena, (blob, fi_off), fi_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), None, gs1b,
                         taps=9, k_chunks=c // 128, n_out=c, src_slot_stride=HW * c, dy_slot_stride=HW * c,
-                        src_pix_stride=c, dy_pix_stride=c, dw_group_stride=9 * c * c, total_nodes=N, partial=part)
+                        src_pix_stride=c, dy_pix_stride=c, dw_group_stride=9 * c * c, total_nodes=N, partial=part,
+                        bias_rows=True)
         gw = torch.empty(c, c, 3, 3, **f32)
-        ops.wgrad_reduce(part, (blob, fi_off), fi_cnt, 1, c, c // 128, 9, gw, 0)
+        ops.wgrad_reduce(part, (blob, fi_off), fi_cnt, 1, c, c // 128, 9, gw, 0, db=gs1b)
         grads['stem.2.weight'], grads['stem.2.bias'] = gw, gs1b
         x_slots = (st['x_rows'], 0) if st.get('x_rows') is not None else sec('SLOTS_IDENT')
         ops.wgrad_tiles(st['x_nhwc'], arena, (blob, it_off), it_cnt, x_slots, sec('SLOTS_DS0'), None, gs0b,
                         taps=9, k_chunks=cpad // 128, n_out=c, src_slot_stride=HW * cpad, dy_slot_stride=HW * c,
-                        src_pix_stride=cpad, dy_pix_stride=c, dw_group_stride=9 * cpad * c, total_nodes=N, partial=part)
+                        src_pix_stride=cpad, dy_pix_stride=c, dw_group_stride=9 * cpad * c, total_nodes=N, partial=part,
+                        bias_rows=True)
         gw = torch.empty(c, cpad, 3, 3, **f32)
-        ops.wgrad_reduce(part, (blob, it_off), it_cnt, 1, c, cpad // 128, 9, gw, 0)
+        ops.wgrad_reduce(part, (blob, it_off), it_cnt, 1, c, cpad // 128, 9, gw, 0, db=gs0b)
         grads['stem.0.weight'] = gw[:, :d['cin']].contiguous() if cpad != d['cin'] else gw
         grads['stem.0.bias'] = gs0b
 

@@ -146,14 +146,29 @@ def _wgrad_params(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, k_c
     return p
 
 
-def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps, partial=None, f32=False, **kw):
+def wgrad_blocks(num_items, n_out, k_chunks, taps):
+    """Blocks of 8192 floats of a partial-block weight-gradient launch: (weight-gradient blocks, blocks of
+    the per-item bias rows that follow them)."""
+    return num_items * (n_out // 64) * k_chunks * taps, (num_items * n_out + 8191) // 8192
+
+
+def wgrad_tiles(src, dy, items, num_items, src_slots, dy_slots, dw, db, *, taps, partial=None, f32=False,
+                bias_rows=False, **kw):
     """items / *_slots are (tensor, word_offset) pairs into an int32 device blob.  With `partial`
     (fp32 workspace of num_items * n_out/64 * k_chunks * taps * 8192 elements) the workgroups store
-    partial blocks for wgrad_reduce and `dw` may be None; otherwise they add into `dw` atomically."""
-    p = _wgrad_params(src, dy, items, num_items, src_slots, dy_slots, dw, db, **kw)
+    partial blocks for wgrad_reduce and `dw` may be None; otherwise they add into `dw` atomically.
+    The bias sums are added to `db` atomically, or, with `bias_rows` (and `partial`, sized by
+    wgrad_blocks), stored per item behind the partial blocks for wgrad_reduce(..., db=) to add in
+    item order."""
+    p = _wgrad_params(src, dy, items, num_items, src_slots, dy_slots, dw, None if bias_rows else db, **kw)
     if partial is not None:
-        assert partial.numel() >= num_items * (kw['n_out'] // 64) * kw['k_chunks'] * taps * 8192
+        dwb, bb = wgrad_blocks(num_items, kw['n_out'], kw['k_chunks'], taps)
+        assert partial.numel() >= (dwb + (bb if bias_rows else 0)) * 8192
         p.partial = partial.data_ptr()
+        if bias_rows:
+            p.bias_block = dwb
+    else:
+        assert not bias_rows
     fn = _lib.load().vqa_wgrad_tiles_f32 if f32 else _lib.load().vqa_wgrad_tiles
     _lib.check(fn(C.byref(p), taps, _stream()))
 
@@ -165,10 +180,15 @@ def wgrad_tiles_noalloc(src, dy, items, num_items, src_slots, dy_slots, db, out,
     _lib.check(_lib.load().vqa_wgrad_tiles_noalloc(C.byref(p), taps, groups, _ptr(out), out_g_stride, _stream()))
 
 
-def wgrad_reduce(partial, items, num_items, groups, n_out, k_chunks, taps, out, out_g_stride):
-    """out[group][n][k][tap] = sum of the group's partial blocks (see wgrad_tiles)."""
+def wgrad_reduce(partial, items, num_items, groups, n_out, k_chunks, taps, out, out_g_stride, db=None):
+    """out[group][n][k][tap] = sum of the group's partial blocks (see wgrad_tiles); db[group][n] =
+    sum of the group's bias rows, when the launch stored them (bias_rows)."""
+    bias = 0
+    if db is not None:
+        assert db.dtype == torch.float32 and db.numel() >= groups * n_out
+        bias = partial.data_ptr() + 4 * 8192 * wgrad_blocks(num_items, n_out, k_chunks, taps)[0]
     _lib.check(_lib.load().vqa_wgrad_reduce(_ptr(partial), items[0].data_ptr() + 4 * items[1], num_items, groups,
-                                            n_out, k_chunks, taps, _ptr(out), out_g_stride, _stream()))
+                                            n_out, k_chunks, taps, _ptr(out), out_g_stride, bias, _ptr(db), _stream()))
 
 
 def unpack_conv_grad(dw, out, groups, n_out, k_in, taps, out_g_stride):
