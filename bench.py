@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--max-nodes', type=int, default=None)
     ap.add_argument('--batches', type=int, default=4, help='distinct resident synthetic batches cycled through')
     ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--no-fwd-bwd-only', action='store_true', help='skip the extra steps without the optimizer that give executor_fwd_bwd')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of vqa_amd.optim.FusedAdam")
     ap.add_argument('--cpu-programs', action='store_true', help='hand the programs over as host tensors (the data loader\'s), '
                     'so that the tile lists of a step are built while the device still runs the step before')
@@ -194,7 +195,7 @@ def main():
         table = ResidentFeatures(torch.cat([b[0] for b in batches]), dev)
         batches = [(table.rows(np.arange(i * a.batch, (i + 1) * a.batch)), p_, an) for i, (_, p_, an) in enumerate(batches)]
 
-    def step(i):
+    def step(i, with_opt=True):
         x, prog, ans = batches[i % len(batches)]
         if opt is not None:
             opt.zero_grad(set_to_none=True)
@@ -205,7 +206,7 @@ def main():
         loss.backward()
         if world > 1 or force_dp:
             step_net.finish_grad_sync()
-        if opt is not None:
+        if opt is not None and with_opt:
             opt.step()
         return loss
 
@@ -264,6 +265,19 @@ def main():
         for k, v in ops.prof_collect().items():
             if k != dominant:
                 prof[k] = v
+    # beside the headline (whole training step): the executor alone, forward + loss + backward without
+    # the optimizer, over a few steps after the timed region - the quantity the 40 % target names
+    fb_ms = None
+    if rank == 0 and world == 1 and opt is not None and not a.no_fwd_bwd_only:
+        nfb = min(a.steps, 10)
+        step(a.warmup + a.steps, with_opt=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nfb):
+            step(a.warmup + a.steps + 1 + i, with_opt=False)
+        torch.cuda.synchronize()
+        fb_ms = (time.perf_counter() - t1) / nfb * 1e3
+        fb_flops = sum(flops_exec_step[(a.warmup + a.steps + 1 + i) % len(batches)] for i in range(nfb)) / nfb
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -357,6 +371,13 @@ def main():
             'hbm': hbm,
             'loss': float(loss.detach()),
         }
+        if fb_ms is not None:
+            out['executor_fwd_bwd'] = {
+                'ms_per_step': fb_ms, 'programs_per_s': a.batch / (fb_ms * 1e-3),
+                'executed_tflops': fb_flops / (fb_ms * 1e-3) / 1e12,
+                'mfma_peak_frac': fb_flops / (fb_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                'note': 'forward + cross-entropy + backward without the optimizer step, %d steps after the timed region; '
+                        'not the headline: `value` is the whole training step' % min(a.steps, 10)}
         if rehearse:
             out['rehearsal'] = 'all ranks on one GPU, gloo through the host: not a measurement'
         if not a.no_cpu_baseline and world == 1:

@@ -33,3 +33,5 @@ def test_one_json_line_with_the_agreed_keys():
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'programs/s' and cb['sample']
     assert cb['forward_only'] > cb['value']       # forward alone is reported beside forward + backward
     assert d['mfma_peak_frac'] <= d['model_flops_frac']      # executed work never exceeds the reference-equivalent count
+    fb = d['executor_fwd_bwd']                                # the executor alone, beside the whole-step headline
+    assert 0 < fb['ms_per_step'] and fb['mfma_peak_frac'] > 0 and 'not the headline' in fb['note']
