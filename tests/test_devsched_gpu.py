@@ -169,6 +169,9 @@ def test_executor_gives_the_same_logits_with_the_schedule_made_on_the_device(voc
         assert net.last_token_counts is None and net.used_fns.is_cuda
         net.raise_for_schedule_error()
         assert torch.equal(got, want) and torch.equal(net.used_fns, want_used.to(net.used_fns.device))
+        # other integer types and strides of the program tensor (Train_model.py hands int64 over)
+        for other in (pt.to(torch.int32), pt.t().contiguous().t(), torch.stack([pt, pt], 2)[:, :, 0]):
+            assert torch.equal(net(x, other), want) and torch.equal(net.used_fns, want_used)
         # a second call through the same workspace with fewer, other rows
         got2 = net(x[5:31], pt[5:31]).clone()
         net.schedule_on_device = False
