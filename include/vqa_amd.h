@@ -237,7 +237,7 @@ int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);
  * slots.  Level L (1..T) runs as vqa_resblock_tiles with level_info + 2L over `tiles` (a node of
  * level L has L nodes of its own below and including it, so a row holds at most T / L of them: no
  * more than N * (T / L) workgroups are of use).  A token id
- * outside [0, V) sets *error to 1 (the host scheduler's VQA_EVOCAB) and the row runs as a lone scene.
+ * outside [0, V) sets bit 0 of *error (the host scheduler's VQA_EVOCAB) and the row runs as a lone scene.
  * Limits: V <= 255, T <= 1023, N * T < 2^26, and programs short enough for a row's parse state
  * (52 T + 16 bytes) to fit LDS; VQA_EINVAL beyond them.
  * ------------------------------------------------------------------------------------------ */
@@ -254,13 +254,19 @@ typedef struct {
     int32_t* bin_cursor;      /* device workspace [T+1][V] */
     int32_t* tiles;           /* device out [N*T][12]: vqa_resblock_tile records, level-major; 16-byte aligned */
     int32_t* cls_tiles;       /* device out [N][8]: vqa_conv_tile records of the classifier's gather; 16-byte aligned */
-    int32_t* error;           /* device out [2]: the flag; the deepest root's level */
+    int32_t* error;           /* device out [2]: flags (1: a token id outside [0, V); 2: an image index
+                                 outside [0, num_images)); the deepest root's level */
+    const int32_t* image_of_row; /* null: row i runs on image i.  Else device [N]: the image of each row
+                                 (candidate scoring, Train_model.py:339-347: K programs on one image):
+                                 stem and scene module run once per image, the rows of an image all read
+                                 its scene output (slots F i, S0 M + i, scene 2M + i / 3M + i, then
+                                 Y = 4M + v ... with M = num_images in place of N) */
     int32_t N, T, V, null_id, start_id, scene_id;
     int32_t spread;           /* 0: every node in its earliest level (1 + its deepest input's), the host
                                  scheduler's levels without VQA_PLAN_BALANCE.  1: rows with slack run
                                  some levels later, a different share of the slack per row, which evens
                                  the launches out */
-    int32_t reserved;
+    int32_t num_images;       /* M, with image_of_row; otherwise ignored (M = N) */
 } vqa_devsched_params;
 
 int vqa_devsched_build(const vqa_devsched_params* p, void* stream);

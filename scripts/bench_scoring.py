@@ -1,6 +1,8 @@
 """Candidate-program scoring (the executor side of the MAPO rollout configuration): M questions x K
 sampled programs each.  Times (a) the reference's call pattern, one executor call per question on an
-expand()-ed image (Train_model.py:339-347), (b) one score_candidates call over all M*K programs.
+expand()-ed image (Train_model.py:339-347), (b) one score_candidates call over all M*K programs with the
+host scheduler (common subtrees of an image's programs run once), (c) the same call with the programs
+scheduled on the device (no copy to the host; every program's own nodes run).
 Programs come from an untrained-sampler-like generator (many ill-formed rows), as the LSTM would emit.
 usage: python scripts/bench_scoring.py [M] [K]"""
 import sys, os, time, json
@@ -53,7 +55,18 @@ with torch.no_grad():
     err = ((a - b).abs().max() / b.abs().max()).item()
     assert err < 1e-3, err
     res = {}
-    for name, fn in (('per_question_calls', loop), ('one_call', batched)):
+    img_dev = torch.from_numpy(img).to(dev, torch.int32)
+
+    def batched_device():
+        net.schedule_on_device = True
+        try:
+            return net.score_candidates(feats, progs, img_dev)
+        finally:
+            net.schedule_on_device = False
+    c = batched_device()
+    torch.cuda.synchronize()
+    assert torch.equal(b, c)
+    for name, fn in (('per_question_calls', loop), ('one_call', batched), ('one_call_schedule_on_device', batched_device)):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()

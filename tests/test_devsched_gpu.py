@@ -203,3 +203,42 @@ def test_sizes_beyond_the_limits_are_refused(vocab):
     sched, used = device_schedule(np.array([[t2i['scene']]], dtype=np.int64), vocab)
     assert used.tolist() == [[1.0]] and sched.level_info.cpu().numpy()[:, ].reshape(-1, 2)[:, 1].sum() == 0
     assert sched.cls_tiles.cpu().numpy()[0] == 2          # the scene output of image 0 (slot 2N + 0)
+
+
+def test_candidate_scoring_with_the_schedule_made_on_the_device(vocab):
+    """score_candidates (Train_model.py:339-347: K sampled programs per image) with the programs left
+    on the device: the stem and the scene module once per image, the logits of the host path (which
+    also shares common subtrees) bit for bit, on an untrained sampler's rows and the quirk rows; the
+    reference's own call shape (an expand()-ed image) takes the same route; an image index out of
+    range raises on request."""
+    from vqa_amd.module_net import ModuleNet
+    t2i = vocab['program_token_to_idx']
+    K, T = 8, 14
+    prog = np.concatenate([synth.synth_sampler_programs(62, 2 * K, len(t2i), T),
+                           np.array(quirk_rows(t2i, T), dtype=np.int64),
+                           synth.synth_programs(63, K, vocab, max_len=T, max_nodes=12)])
+    M = prog.shape[0] // K
+    img = torch.arange(M).repeat_interleave(K)
+    x = torch.from_numpy(synth.synth_features(64, M, DIMS['feature_dim'])).cuda()
+    net = ModuleNet(False, vocab, **DIMS)
+    net.load_state_dict(synth.synth_state_dict(65, vocab, **DIMS))
+    net.cuda().eval()
+    pt = torch.from_numpy(prog).cuda()
+    with torch.no_grad():
+        want = net.score_candidates(x, pt, img).clone()
+        want_used = net.used_fns.clone()
+        full = net(x[img.cuda()], pt).clone()
+        net.schedule_on_device = True
+        for index in (img, img.cuda(), img.tolist()):
+            got = net.score_candidates(x, pt, index)
+            assert net.last_token_counts is None            # the device path ran
+            net.raise_for_schedule_error()
+            assert torch.equal(got, want) and torch.equal(got, full)
+            assert torch.equal(net.used_fns, want_used.to(net.used_fns.device))
+        one = net(x[1:2].expand(K, -1, -1, -1), pt[K:2 * K])
+        assert net.last_token_counts is None and torch.equal(one, want[K:2 * K])
+        bad = img.clone()
+        bad[5] = M
+        net.score_candidates(x, pt, bad)
+        with pytest.raises(IndexError):
+            net.raise_for_schedule_error()

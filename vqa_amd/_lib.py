@@ -63,8 +63,8 @@ class ResblockParams(C.Structure):
 
 class DevschedParams(C.Structure):
     _fields_ = [(n, vp) for n in ('programs', 'arity', 'used', 'node', 'counts', 'hist', 'row_base',
-                                  'level_info', 'bin_off', 'bin_cursor', 'tiles', 'cls_tiles', 'error')] + \
-               [(n, i32) for n in ('N', 'T', 'V', 'null_id', 'start_id', 'scene_id', 'spread', 'reserved')]
+                                  'level_info', 'bin_off', 'bin_cursor', 'tiles', 'cls_tiles', 'error', 'image_of_row')] + \
+               [(n, i32) for n in ('N', 'T', 'V', 'null_id', 'start_id', 'scene_id', 'spread', 'num_images')]
 
 
 SEC = {name: i for i, name in enumerate((

@@ -222,11 +222,17 @@ __global__ __launch_bounds__(256) void devsched_emit_kernel(vqa_devsched_params 
     if (k >= cnt.x) return;
     const int4* nodes = (const int4*)p.node + (int64_t)row * R;
     const int4 nd = nodes[k];
-    const int N = p.N, nvmax = p.N * p.T;
+    // (slot bases count images: M of them when several rows share one, else one per row)
+    const int N = p.image_of_row ? p.num_images : p.N, nvmax = p.N * p.T;
+    int img = row;
+    if (p.image_of_row) {
+        img = p.image_of_row[row];
+        if (img < 0 || img >= N) { atomicOr(p.error, 2); img = 0; }
+    }
     const int tok = nd.x & 255, L = final_level(p, row, cnt.w >> 16, nd.x >> 8);
     const int vbase = p.row_base[row * 2], bbase = p.row_base[row * 2 + 1];
     const bool scene = tok == p.scene_id;
-    const int y = scene ? 2 * N + row : 4 * N + vbase + (nd.w & 0xffff);
+    const int y = scene ? 2 * N + img : 4 * N + vbase + (nd.w & 0xffff);
     if (k == (cnt.w & 0xffff)) {
         // the classifier's gather: root map of the row -> row of the classifier input (the torch.cat
         // of Module_Model.py:232)
@@ -236,12 +242,12 @@ __global__ __launch_bounds__(256) void devsched_emit_kernel(vqa_devsched_params 
     }
     if (scene) return;
     const int4 k0 = nodes[nd.y];
-    const int y0 = (k0.x & 255) == p.scene_id ? 2 * N + row : 4 * N + vbase + (k0.w & 0xffff);
+    const int y0 = (k0.x & 255) == p.scene_id ? 2 * N + img : 4 * N + vbase + (k0.w & 0xffff);
     const bool bin = nd.z >= 0;
     int y1 = -1;
     if (bin) {
         const int4 k1 = nodes[nd.z];
-        y1 = (k1.x & 255) == p.scene_id ? 2 * N + row : 4 * N + vbase + (k1.w & 0xffff);
+        y1 = (k1.x & 255) == p.scene_id ? 2 * N + img : 4 * N + vbase + (k1.w & 0xffff);
     }
     const int in = bin ? 4 * N + 2 * nvmax + bbase + (nd.w >> 16) : y0;
     const int pos = p.bin_off[L * p.V + tok] + atomicAdd(p.bin_cursor + L * p.V + tok, 1);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void devsched_emit_kernel(vqa_devsched_params 
 extern "C" int vqa_devsched_build(const vqa_devsched_params* p, void* stream) {
     if (!p || !p->programs || !p->arity || !p->used || !p->node || !p->counts || !p->hist || !p->row_base ||
         !p->level_info || !p->bin_off || !p->bin_cursor || !p->tiles || !p->cls_tiles || !p->error || p->N <= 0 ||
-        p->T <= 0 || p->V <= 0 || p->V > 255 || p->T + 1 > 1024 || (int64_t)p->N * p->T >= (1 << 26) ||
+        p->T <= 0 || p->V <= 0 || p->V > 255 || (p->image_of_row && p->num_images <= 0) || p->T + 1 > 1024 || (int64_t)p->N * p->T >= (1 << 26) ||
         (((uintptr_t)p->node | (uintptr_t)p->counts | (uintptr_t)p->tiles | (uintptr_t)p->cls_tiles) & 15)) {
         vqa_set_error("vqa_devsched_build: bad argument (sizes, null pointer, or node / counts / tiles / cls_tiles not 16-byte aligned)");
         return VQA_EINVAL;

@@ -487,6 +487,18 @@ class ModuleNet(nn.Module):
                                'tensor (no CPU fallback)')
         if self.precision != 'bf16':
             raise NotImplementedError('shared-image scoring is built for the bf16 path')
+        if (self.schedule_on_device and program.is_cuda and program.device == x.device and self._dims['c'] == 128 and
+                self.fuse_residual_body):
+            # programs stay on the device (see schedule_on_device): the stem and the scene module run
+            # once per image, every program's own nodes run (common subtrees of an image's programs
+            # are not searched for on the device); an image index out of range raises from
+            # raise_for_schedule_error()
+            img = torch.as_tensor(image_index).detach().to(x.device, torch.int32, non_blocking=True).contiguous()
+            if img.numel() != program.size(0):
+                raise ValueError('image_index must have one entry per program')
+            _lib.load()
+            with torch.no_grad():
+                return _ExecFn.apply(self, x, program, False, img, *[p for _, p in self._param_groups()])
         img = torch.as_tensor(image_index).detach().to('cpu', torch.int32).contiguous()
         if img.numel() != program.size(0):
             raise ValueError('image_index must have one entry per program')
@@ -601,7 +613,8 @@ class ModuleNet(nn.Module):
             ready.record(cur)
             side.wait_event(ready)
             fused = c == 128 and self.fuse_residual_body
-            devs = (self.schedule_on_device and fused and not need_grad and image_index is None and
+            dev_images = isinstance(image_index, torch.Tensor) and image_index.is_cuda
+            devs = (self.schedule_on_device and fused and not need_grad and (image_index is None or dev_images) and
                     program.is_cuda and program.device == dev)
             if devs:
                 # the programs stay where they are: parsed and bucketed by kernels on the side stream,
@@ -612,10 +625,13 @@ class ModuleNet(nn.Module):
                 t2i = self.vocab['program_token_to_idx']
                 with torch.cuda.stream(side):
                     ops.devsched_build(prog_dev, self._arity_dev, used, sched, t2i['<NULL>'], t2i['<START>'], t2i['scene'],
-                                       spread=self.device_spread_levels)
+                                       spread=self.device_spread_levels, image_of_row=image_index if dev_images else None,
+                                       num_images=M)
                     sched_done = torch.cuda.Event()
                     sched_done.record(side)
                 prog_dev.record_stream(side)
+                if dev_images:
+                    image_index.record_stream(side)
             elif program.is_cuda:
                 prog_dev = program.detach().to(torch.int64).contiguous()
                 with torch.cuda.stream(side):
@@ -634,7 +650,7 @@ class ModuleNet(nn.Module):
             stem_elems = 4 * M * HW * c      # stem maps S0, F and the scene module's H, Y per image
             # (with the schedule made on the device the host does not learn the node counts: slots
             # have fixed strides, a row has at most T nodes that are not the scene module)
-            dev_slots = 4 * N + 3 * N * T
+            dev_slots = 4 * M + 3 * N * T
             arena_full = ws.get_capacity('arena', dev_slots * HW * c if devs else stem_elems, torch.bfloat16, dev)
             xn, rows, xs = self._stem_input(x, ws, M, dev)
             st['x_nhwc'], st['x_rows'] = xn, rows
@@ -833,8 +849,11 @@ class ModuleNet(nn.Module):
         lookup (Module_Model.py:200) and the host scheduler raise at once.  The logits of such a
         call are those of a lone scene module for the offending rows."""
         e = self.schedule_error
-        if e is not None and int(e.item()):
+        flags = int(e.item()) if e is not None else 0
+        if flags & 1:
             raise KeyError('program token id outside the vocabulary')
+        if flags & 2:
+            raise IndexError('image_index out of range')
 
     def _params_changed(self):
         """Parameters are about to change without their version counters moving (a backward pass is

@@ -98,9 +98,11 @@ class DeviceSchedule:
         self.row_base, self.bin_off, self.bin_cursor = take(N * 2), take((T + 1) * V), take((T + 1) * V)
 
 
-def devsched_build(programs, arity, used, sched, null_id, start_id, scene_id, spread=False):
+def devsched_build(programs, arity, used, sched, null_id, start_id, scene_id, spread=False, image_of_row=None,
+                   num_images=0):
     """Programs in device memory -> tile lists in device memory (vqa_devsched_build): `programs`
-    int64 [N][T], `arity` int8 [V], `used` float32 [N][T] out, `sched` a DeviceSchedule."""
+    int64 [N][T], `arity` int8 [V], `used` float32 [N][T] out, `sched` a DeviceSchedule; `image_of_row`
+    int32 [N] when rows share images (num_images of them)."""
     _need_cuda(programs, arity, used, sched.tiles)
     N, T = programs.shape
     assert programs.dtype == torch.int64 and programs.is_contiguous() and arity.dtype == torch.int8
@@ -113,6 +115,10 @@ def devsched_build(programs, arity, used, sched, null_id, start_id, scene_id, sp
         setattr(p, k, getattr(sched, k).data_ptr())
     p.N, p.T, p.V, p.null_id, p.start_id, p.scene_id = N, T, sched.V, null_id, start_id, scene_id
     p.spread = int(spread)
+    if image_of_row is not None:
+        _need_cuda(image_of_row)
+        assert image_of_row.dtype == torch.int32 and image_of_row.is_contiguous() and image_of_row.numel() == N
+        p.image_of_row, p.num_images = image_of_row.data_ptr(), num_images
     _lib.check(_lib.load().vqa_devsched_build(C.byref(p), _stream()))
 
 
