@@ -142,43 +142,64 @@ class FusedAdam(torch.optim.Optimizer):
                 cols[0].append(p.data_ptr()); cols[1].append(g.data_ptr()); cols[2].append(r[4]); cols[3].append(r[5])
                 cols[4].append(r[2]); cols[5].append(sc[0]); cols[6].append(sc[1]); cols[7].append(idx)
                 keep.append(g)
-            for dev, cols in by_dev.items():
-                n = len(cols[0])
-                ckey = (gi, dev, tuple(cols[7]))
-                if self._chunks_key != ckey:      # the chunk list depends on which tensors take part only
-                    numel = np.asarray(cols[4], dtype=np.int64)
-                    nch = (numel + _CHUNK_ELEMS - 1) // _CHUNK_ELEMS
-                    ck = np.zeros(int(nch.sum()), dtype=_CHUNK)
-                    ck['tensor'] = np.repeat(np.arange(n, dtype=np.int32), nch)
-                    first = np.concatenate([[0], np.cumsum(nch)[:-1]])
-                    ck['offset'] = (np.arange(len(ck)) - np.repeat(first, nch)) * _CHUNK_ELEMS
-                    self._chunks_key, self._chunks = ckey, ck.view(np.uint8)
-                cb = self._chunks
-                off = (n * _TENSOR.itemsize + 255) // 256 * 256
-                ent = self._tables(dev, off + len(cb))
+            # one table upload per device: the tensor table and chunk list of vqa_adam_tensors, then the
+            # rows of every vqa_adam_conv_pack launch, each part 256-byte aligned
+            for dev in set(by_dev) | {d for d, _ in conv}:
+                parts = []               # (offset, byte count, fill function, launch function)
+                total = 0
+
+                def add(nbytes, fill, launch):
+                    nonlocal total
+                    parts.append((total, nbytes, fill, launch))
+                    total += (nbytes + 255) // 256 * 256
+                cols = by_dev.get(dev)
+                if cols is not None:
+                    n = len(cols[0])
+                    ckey = (gi, dev, tuple(cols[7]))
+                    if self._chunks_key != ckey:      # the chunk list depends on which tensors take part only
+                        numel = np.asarray(cols[4], dtype=np.int64)
+                        nch = (numel + _CHUNK_ELEMS - 1) // _CHUNK_ELEMS
+                        ck = np.zeros(int(nch.sum()), dtype=_CHUNK)
+                        ck['tensor'] = np.repeat(np.arange(n, dtype=np.int32), nch)
+                        first = np.concatenate([[0], np.cumsum(nch)[:-1]])
+                        ck['offset'] = (np.arange(len(ck)) - np.repeat(first, nch)) * _CHUNK_ELEMS
+                        self._chunks_key, self._chunks = ckey, ck.view(np.uint8)
+                    cb = self._chunks
+                    off = (n * _TENSOR.itemsize + 255) // 256 * 256
+
+                    def fill_tensors(view, cols=cols, n=n, cb=cb, off=off):
+                        tt = view[:n * _TENSOR.itemsize].view(_TENSOR)
+                        tt['p'], tt['g'], tt['m'], tt['v'] = cols[0], cols[1], cols[2], cols[3]
+                        tt['numel'], tt['step_size'], tt['inv_bc2_sqrt'] = cols[4], cols[5], cols[6]
+                        view[off:off + len(cb)] = cb
+
+                    def launch_tensors(ptr, stream, cb=cb, off=off):
+                        _lib.check(lib.vqa_adam_tensors(ptr, ptr + off, len(cb) // _CHUNK.itemsize,
+                                                        wd, b1, b2, eps, stream.cuda_stream))
+                    add(off + len(cb), fill_tensors, launch_tensors)
+                for (d, kind), rows in conv.items():
+                    if d != dev:
+                        continue
+
+                    def fill_conv(view, rows=rows):
+                        tt = view[:len(rows) * _CONV.itemsize].view(_CONV)
+                        for j, name in enumerate(_CONV.names):
+                            tt[name] = [row[j] for row in rows]
+
+                    def launch_conv(ptr, stream, rows=rows, kind=kind):
+                        cout, cin, taps = shapes[kind]
+                        _lib.check(lib.vqa_adam_conv_pack(ptr, len(rows), cout, cin, taps, wd, b1, b2, eps, stream.cuda_stream))
+                    add(len(rows) * _CONV.itemsize, fill_conv, launch_conv)
+                ent = self._tables(dev, total)
                 devbuf, hostnp = ent[1], ent[3]
-                tt = hostnp[:n * _TENSOR.itemsize].view(_TENSOR)
-                tt['p'], tt['g'], tt['m'], tt['v'] = cols[0], cols[1], cols[2], cols[3]
-                tt['numel'], tt['step_size'], tt['inv_bc2_sqrt'] = cols[4], cols[5], cols[6]
-                hostnp[off:off + len(cb)] = cb
+                for o, nb, fill, _ in parts:
+                    fill(hostnp[o:o + nb])
                 stream = torch.cuda.current_stream(dev)
-                devbuf[:off + len(cb)].copy_(ent[0][:off + len(cb)], non_blocking=True)
+                devbuf[:total].copy_(ent[0][:total], non_blocking=True)
                 ent[2] = torch.cuda.Event()
                 ent[2].record(stream)
-                _lib.check(lib.vqa_adam_tensors(devbuf.data_ptr(), devbuf.data_ptr() + off, len(cb) // _CHUNK.itemsize,
-                                                wd, b1, b2, eps, stream.cuda_stream))
-            for (dev, kind), rows in conv.items():
-                n = len(rows)
-                ent = self._tables((dev, kind), n * _CONV.itemsize)
-                tt = ent[3][:n * _CONV.itemsize].view(_CONV)
-                for j, name in enumerate(_CONV.names):
-                    tt[name] = [row[j] for row in rows]
-                stream = torch.cuda.current_stream(dev)
-                ent[1][:n * _CONV.itemsize].copy_(ent[0][:n * _CONV.itemsize], non_blocking=True)
-                ent[2] = torch.cuda.Event()
-                ent[2].record(stream)
-                cout, cin, taps = shapes[kind]
-                _lib.check(lib.vqa_adam_conv_pack(ent[1].data_ptr(), n, cout, cin, taps, wd, b1, b2, eps, stream.cuda_stream))
+                for o, _, _, launch in parts:
+                    launch(devbuf.data_ptr() + o, stream)
             self._keep = keep            # gradients stay referenced until the next step (kernels still queued)
         if ex is not None:
             ex._packed_stale = True      # parameters changed without their version counters moving
