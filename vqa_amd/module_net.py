@@ -251,7 +251,7 @@ class ModuleNet(nn.Module):
         self.last_token_counts = None
         # programs that are in device memory (a sampler's output) are parsed and bucketed there, with
         # no copy to the host, when no gradient is asked for (bf16, module width 128): same logits bit
-        # for bit as the host scheduler without balance_levels.  used_fns stays a device tensor, and a
+        # for bit as with the host scheduler.  used_fns stays a device tensor, and a
         # token id outside the vocabulary cannot raise from an asynchronous launch: it sets
         # schedule_error (see raise_for_schedule_error)
         self.schedule_on_device = False
