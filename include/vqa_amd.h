@@ -334,7 +334,7 @@ int vqa_wgrad_tiles_f32(const vqa_wgrad_params* p, int32_t taps, void* stream);
  * of the group's items; a group without items gets zeros.  items / num_items / n_out / k_chunks as
  * in the vqa_wgrad_tiles call that wrote `partial`.  bias_partial / db: null, or the [item][n_out]
  * sums that call stored (its partial + bias_block * 8192) and the fp32 [groups][n_out] array that
- * receives their per-group sums (written whole; n_out <= 512). */
+ * receives their per-group sums (written whole; n_out <= 2048). */
 int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* items, int32_t num_items,
                      int32_t groups, int32_t n_out, int32_t k_chunks, int32_t taps, float* out,
                      int64_t out_g_stride, const float* bias_partial, float* db, void* stream);

@@ -34,3 +34,4 @@ def test_two_runs_of_a_training_step_give_the_same_bits(vocab):
         assert grads.keys() == runs[0][1].keys()
         for k, g in grads.items():
             assert torch.equal(g, runs[0][1][k]), k
+

@@ -521,3 +521,31 @@ def test_transpose_f32_batched_with_padded_rows():
     torch.cuda.synchronize()
     assert torch.equal(out[:, :, :rows].cpu(), x.permute(0, 2, 1))
     assert float(out[:, :, rows:].max()) == -1.0           # the padding is left alone
+
+
+def test_wgrad1x1_wide_output_bias_rows():
+    """A 1x1 weight gradient with 1024 output channels (a wide classifier projection): the bias sums
+    stored per item and added by the reduction's bias workgroup (four output channels per thread)
+    equal the atomically accumulated ones and torch's."""
+    from vqa_amd import ops
+    C, P, S = 128, 1024, 6
+    x = bf(rnd((S, C, 14, 14), 30))
+    dy = bf(rnd((S, P, 14, 14), 31))
+    src, dyt = to_slots(x), to_slots(dy)
+    items = tiles_tensor([[0, 0, 4, 0], [0, 4, 2, 0]])
+    slots = tiles_tensor(list(range(S)))
+    kw = dict(taps=1, k_chunks=1, n_out=P, src_slot_stride=HW * C, dy_slot_stride=HW * P, src_pix_stride=C,
+              dy_pix_stride=P, dw_group_stride=C * P)
+    dw = torch.zeros(1, 1, C, P, device=dev())
+    db = torch.zeros(1, P, device=dev())
+    ops.wgrad_tiles(src, dyt, (items, 0), 2, (slots, 0), (slots, 0), dw, db, **kw)
+    part = torch.full((sum(ops.wgrad_blocks(2, P, 1, 1)) * 8192,), float('nan'), device=dev())
+    db2 = torch.full((1, P), 7.0, device=dev())
+    out = torch.empty(P, C, 1, 1, device=dev())
+    ops.wgrad_tiles(src, dyt, (items, 0), 2, (slots, 0), (slots, 0), None, db2, partial=part, bias_rows=True, **kw)
+    ops.wgrad_reduce(part, (items, 0), 2, 1, P, 1, 1, out, 0, db=db2)
+    torch.cuda.synchronize()
+    rw, rb = _wgrad_ref(x, dy, (P, C, 1, 1), 0)
+    close(db2.cpu()[0], rb, 5e-3)
+    close(db2.cpu(), db.cpu(), 1e-5)
+    close(out.cpu(), rw, 5e-3)

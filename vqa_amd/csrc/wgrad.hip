@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     // (inside one of those it would be the launch's tail); thread = output channel (two of them when
     // n_out > 256), the items' rows added in list order
     const bool do_bias = db != nullptr && blockIdx.x == gridDim.x - 1;
-    float bacc[2] = {0.f, 0.f};
+    float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // n_out <= 2048
     for (int base = 0; base < num_items; base += 256) {
         const int j = base + tid;
         const bool mine = j < num_items && items[j].group == grp;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         if (do_bias) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < 8; h++) {
                 const int o = tid + 256 * h;
                 if (o < n_out)
                     for (int k = 0; k < n; k += 8) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     if (do_bias) {
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int h = 0; h < 8; h++)
             if (tid + 256 * h < n_out) db[(int64_t)grp * n_out + tid + 256 * h] = bacc[h];
         return;
     }
@@ -364,7 +364,7 @@ extern "C" int vqa_wgrad_reduce(const float* partial, const vqa_wgrad_item* item
                                 int64_t out_g_stride, const float* bias_partial, float* db, void* stream) {
     if (!partial || !items || !out || num_items < 0 || groups <= 0 || n_out <= 0 || n_out % 64 != 0 ||
         k_chunks <= 0 || (taps != 9 && taps != 1) || ((db != nullptr) != (bias_partial != nullptr)) ||
-        (db && n_out > 512)) {
+        (db && n_out > 2048)) {
         vqa_set_error("vqa_wgrad_reduce: bad argument");
         return VQA_EINVAL;
     }
