@@ -78,6 +78,7 @@ class DataParallelExecutor:
         self._by_name = dict(self._params)
         self._flat = None
         self._layout = None
+        self._zeros = None
         self._groups = []            # (array, {name: row}) handed over by the executor this step
         self._grouped_names = set()  # names that arrive as rows of such arrays (fixed after the first step)
         self._small_groups = []
@@ -206,13 +207,21 @@ class DataParallelExecutor:
     def _on_backward_done(self):
         dev = next(iter(self._small.values())).device if self._small else self._params[0][1].device
         self._ensure_flat(dev)
-        self._flat.zero_()
-        for n, g in self._small.items():
-            off, cnt = self._layout[n]
-            self._flat[off:off + cnt].copy_(g.reshape(-1))
-        for k, (array, _) in enumerate(self._small_groups):
-            off, cnt = self._layout[('group', k)]
-            self._flat[off:off + cnt].copy_(array.reshape(-1))
+        # the bucket in one launch: the pieces in layout order, zeros where this step has no gradient
+        parts = []
+        for key, (off, cnt) in self._layout.items():
+            if isinstance(key, tuple):
+                g = self._small_groups[key[1]][0]
+            else:
+                g = self._small.get(key)
+            if g is None:
+                z = self._zeros
+                if z is None or z.numel() < cnt or z.device != dev:
+                    z = self._zeros = torch.zeros(max(cnt, 1 << 16), dtype=torch.float32, device=dev)
+                g = z[:cnt]
+            parts.append(g.reshape(-1))
+        if parts:
+            torch.cat(parts, out=self._flat)
         self._reduce(self._flat)
 
     # ---------------------------------------------------------------- after loss.backward()
