@@ -253,10 +253,9 @@ class DataParallelExecutor:
         if not self._avg:
             for array, _ in groups:
                 array.mul_(scale)            # reduced in place as sums
-        for k, (array, rows) in enumerate(self._small_groups):     # these travelled in the flat bucket
-            off, cnt = self._layout[('group', k)]
-            array.copy_(self._flat[off:off + cnt].view(array.shape))
-            groups.append((array, rows))
+        for k, (array, rows) in enumerate(self._small_groups):     # these travelled in the flat bucket:
+            off, cnt = self._layout[('group', k)]                  # their parameters' .grad become views of it
+            groups.append((self._flat[off:off + cnt].view(array.shape), rows))
         # A parameter whose token this rank used already has its row of the array as .grad (autograd
         # installed it; the reduction was in place): only the others are touched.
         by_name, token_of = self._by_name, self._token_of
