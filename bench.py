@@ -43,6 +43,9 @@ def parse():
     ap.add_argument('--max-nodes', type=int, default=None)
     ap.add_argument('--batches', type=int, default=4, help='distinct resident synthetic batches cycled through')
     ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--dp-replicated-update', action='store_true',
+                    help="N > 1: every rank all-reduces the first linear layer's gradient and updates the whole layer; default: "
+                         'reduce-scatter by rows, each rank updates its rows, the updated bf16 rows are all-gathered (same arithmetic)')
     ap.add_argument('--no-fwd-bwd-only', action='store_true', help='skip the extra steps without the optimizer that give executor_fwd_bwd')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of vqa_amd.optim.FusedAdam")
     ap.add_argument('--cpu-programs', action='store_true', help='hand the programs over as host tensors (the data loader\'s), '
@@ -137,22 +140,14 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29533')
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         elif rehearse:
+            # device tensors cross through the host, with the timing of an asynchronous backend
+            # (tests/dp_rig.py): gloo's own device-tensor path stalls now and then with two processes on one GPU
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests'))
+            import dp_rig
+            import faulthandler
+            faulthandler.dump_traceback_later(150, exit=True)
             dist.init_process_group('gloo')
-            whole = dist.all_reduce
-
-            class _Done:
-                def wait(self):
-                    return True
-
-            def staged(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
-                if not t.is_cuda:
-                    return whole(t, op=op, group=group, async_op=async_op)
-                torch.cuda.current_stream().synchronize()
-                h = t.detach().cpu()
-                whole(h, op=op, group=group)
-                t.copy_(h)
-                return _Done() if async_op else None
-            dist.all_reduce = staged
+            dp_rig.patch_collectives()
         else:
             dist.init_process_group('nccl', device_id=dev)
 
@@ -166,7 +161,8 @@ def main():
     step_net = net
     if world > 1 or force_dp:
         from vqa_amd.dp import DataParallelExecutor
-        step_net = DataParallelExecutor(net, big_transport=a.dp_transport, big_algo=a.dp_algo)
+        step_net = DataParallelExecutor(net, big_transport=a.dp_transport, big_algo=a.dp_algo,
+                                        shard_big_update=not a.dp_replicated_update and not a.torch_adam and not a.no_optimizer)
     opt = None
     if not a.no_optimizer:
         # Train_model.py:165-167: Adam, lr 1e-4, weight_decay 5e-5
@@ -351,7 +347,11 @@ def main():
                                       '[N,1024,14,14] fp32 resident in HBM' if a.features == 'fp32' else
                                       'rows of a bf16 [R,196,1024] table resident in HBM, read in place',
                                       'in host memory' if a.cpu_programs else 'resident in HBM'),
-                       'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
+                       'global_batch': a.batch * world,
+                       'parallelism': 'dp%d' % world + ('' if world == 1 else (
+                           ', every rank updates all parameters' if (a.dp_replicated_update or a.torch_adam or a.no_optimizer) else
+                           ", first linear layer's gradient reduce-scattered by rows, its Adam update and bf16 copy "
+                           'sharded over the ranks (same arithmetic as the replicated update)'))},
             # executed: what the device runs (the scene nodes of a sample are one computation);
             # model: what the reference's per-node execution of the same programs would do
             'executed_tflops': flops_exec * world / dt / 1e12,

@@ -46,6 +46,11 @@ def join(rank, world, port):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     if os.environ.get('VQA_DP_RIG_DIRECT'):      # gloo's own device-tensor path (see the module docstring)
         return
+    patch_collectives()
+
+
+def patch_collectives():
+    """Routes the three collectives the wrapper uses on device tensors through the host (see above)."""
     all_reduce, reduce_scatter, all_gather = dist.all_reduce, dist.reduce_scatter_tensor, dist.all_gather_into_tensor
 
     def finish(w, async_op):

@@ -28,12 +28,14 @@ def test_single_rank_rccl_matches_plain_training(vocab):
         dims = dict(feature_dim=(128, 14, 14), module_dim=128, classifier_proj_dim=128, classifier_fc_layers=(128,))
         sd = synth.synth_state_dict(41, vocab, **dims)
         runs = []
-        for wrapped in (False, True, ('bf16', 'reduce_scatter')):
+        for wrapped in (False, True, ('bf16', 'reduce_scatter'), 'sharded'):
             net = ModuleNet(False, vocab, **dims)
             net.load_state_dict(sd)
             net.to(dev).train()
             if wrapped is True:
                 step_net = DataParallelExecutor(net, direct_bytes=1 << 20)
+            elif wrapped == 'sharded':   # reduce-scatter of the large gradient, Adam on this rank's rows, all-gather of the bf16 rows
+                step_net = DataParallelExecutor(net, direct_bytes=1 << 20, shard_big_update=True)
             elif wrapped:      # the large gradient as a bf16 copy through RCCL's reduce-scatter + all-gather
                 step_net = DataParallelExecutor(net, direct_bytes=1 << 20, big_transport=wrapped[0], big_algo=wrapped[1])
             else:
@@ -52,9 +54,16 @@ def test_single_rank_rccl_matches_plain_training(vocab):
                 unused = [n for n, p in net.named_parameters() if p.grad is None]
                 opt.step()
                 losses.append(loss.item())
+            if wrapped == 'sharded':
+                step_net.gather_sharded_state(opt)
             torch.cuda.synchronize()
             runs.append((losses, unused, {k: v.detach().clone() for k, v in net.state_dict().items()}))
-        (la, ua, sa), (lb, ub, sb), (lc, uc, sc) = runs
+        (la, ua, sa), (lb, ub, sb), (lc, uc, sc), (ld, ud, sd_) = runs
+        assert sorted(ud) == sorted(ua + ['classifier.3.weight'])   # that gradient lives as this rank's rows
+        for a, b in zip(la, ld):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (la, ld)
+        for k in sa:
+            torch.testing.assert_close(sa[k], sd_[k], rtol=2e-3, atol=2e-5, msg=k)
         assert uc == ua
         for a, c in zip(la, lc):       # one bf16 rounding of one gradient: the trajectory moves by less than bf16 noise
             assert abs(a - c) <= 5e-3 * max(1.0, abs(a)), (la, lc)

@@ -28,7 +28,7 @@ def _batch(step, dev):
     return prog.to(dev), x.to(dev), ans.to(dev)
 
 
-def _train(rank, world, out_path, big=('fp32', 'all_reduce')):
+def _train(rank, world, out_path, big=('fp32', 'all_reduce'), shard=False):
     """Runs STEPS steps on this rank's rows; returns (losses, step-1 gradients, final parameters)."""
     import torch.distributed as dist
     from vqa_amd.dp import DataParallelExecutor, shard_rows
@@ -39,7 +39,8 @@ def _train(rank, world, out_path, big=('fp32', 'all_reduce')):
     net = ModuleNet(False, vocab, **DIMS)
     net.load_state_dict(synth.synth_state_dict(43, vocab, **DIMS))
     net.to(dev).train()
-    step_net = (DataParallelExecutor(net, direct_bytes=1 << 20, big_transport=big[0], big_algo=big[1])
+    step_net = (DataParallelExecutor(net, direct_bytes=1 << 20, big_transport=big[0], big_algo=big[1],
+                                     shard_big_update=shard)
                 if world > 1 else net)
     opt = FusedAdam(net.parameters(), lr=1e-3, weight_decay=5e-5, executor=net)
     lo, hi = shard_rows(BATCH, rank, world)
@@ -59,18 +60,22 @@ def _train(rank, world, out_path, big=('fp32', 'all_reduce')):
                            for n, p in net.named_parameters()}
         opt.step()
         losses.append(float(loss.detach()))
+    if world > 1:
+        step_net.gather_sharded_state(opt)       # (nothing to do unless the update was sharded)
     torch.cuda.synchronize()
-    res = (losses, first_grads, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    res = (losses, first_grads, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
+           {k: opt.state[p][k].detach().cpu().clone() for p in [net.classifier[net._fc_idx[0]].weight]
+            for k in ('exp_avg', 'exp_avg_sq')})
     if out_path is not None:
         torch.save(res, out_path)
     return res
 
 
-def _rank_main(rank, world, port, out_dir, big):
+def _rank_main(rank, world, port, out_dir, big, shard=False):
     import dp_rig
     dp_rig.join(rank, world, port)
     try:
-        _train(rank, world, os.path.join(out_dir, 'rank%d.pt' % rank), big)
+        _train(rank, world, os.path.join(out_dir, 'rank%d.pt' % rank), big, shard)
     finally:
         dp_rig.leave()
 
@@ -102,3 +107,32 @@ def test_two_ranks_match_whole_batch_training(big):
     # the trajectory stays together (bf16 arithmetic, different tile grouping per batch split)
     for a, b in zip(r0[0], whole[0]):
         assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (r0[0], whole[0])
+
+
+def test_two_ranks_with_the_first_linear_layer_updated_in_slices():
+    """shard_big_update: the first linear layer's gradient is reduce-scattered by rows, each rank runs
+    Adam on its rows and the updated bf16 rows are all-gathered under the next forward.  The losses
+    follow whole-batch training, both ranks end with the same parameters and Adam moments once the
+    master copy is gathered, and those equal the replicated update's to fp32 rounding."""
+    import torch.multiprocessing as mp
+    runs = {}
+    for shard in (False, True):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_rank_main, args=(2, port, d, ('fp32', 'all_reduce'), shard), nprocs=2, join=True)
+            runs[shard] = [torch.load(os.path.join(d, 'rank%d.pt' % r), weights_only=True) for r in (0, 1)]
+    r0, r1 = runs[True]
+    for k in r0[2]:
+        assert torch.equal(r0[2][k], r1[2][k]), k
+    for k in r0[3]:
+        assert torch.equal(r0[3][k], r1[3][k]), k
+    assert r0[0] == r1[0]
+    assert r0[1]['classifier.3.weight'] is None            # the gradient lives as per-rank rows
+    rep = runs[False][0]
+    for a, b in zip(r0[0], rep[0]):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (r0[0], rep[0])
+    for k in r0[2]:
+        d_ = float((r0[2][k] - rep[2][k]).abs().max())
+        assert d_ <= 2e-5 * max(1.0, float(rep[2][k].abs().max())), (k, d_)
+    for k in r0[3]:
+        assert float((r0[3][k] - rep[3][k]).abs().max()) <= 1e-5 * max(1e-3, float(rep[3][k].abs().max())), k

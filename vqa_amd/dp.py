@@ -45,9 +45,18 @@ def loss_weight(n, rank, world):
 
 
 class DataParallelExecutor:
-    def __init__(self, net, process_group=None, direct_bytes=32 << 20, big_transport='fp32', big_algo='all_reduce'):
-        """big_transport / big_algo apply to gradients of at least `direct_bytes` (the first linear
-        layer's 411 MB weight gradient, 87 % of all gradient bytes):
+    def __init__(self, net, process_group=None, direct_bytes=32 << 20, big_transport='fp32', big_algo='all_reduce',
+                 shard_big_update=False):
+        """shard_big_update (with vqa_amd.optim.FusedAdam(executor=net)): the first linear layer's
+        gradient is reduce-scattered by rows instead of all-reduced, each rank runs Adam on its 1/N of
+        that layer (N ranks updating the same 103 M parameters N times over is the replicated step's
+        largest non-MFMA cost), and what is all-gathered is the updated bf16 copy the kernels read -
+        under the next forward, which only needs it at the classifier.  Same arithmetic as the
+        replicated update.  The fp32 master copy, its gradient and its Adam state are then current on
+        the owning rank only: gather_sharded_state() before reading or saving them.
+
+        big_transport / big_algo apply to gradients of at least `direct_bytes` (the first linear
+        layer's 411 MB weight gradient, 87 % of all gradient bytes) when they are not sharded:
           big_transport 'fp32' (default: N ranks give the gradients of one rank on the whole batch to
               fp32 rounding) or 'bf16' (the gradient crosses the links as bf16 - half the wire time,
               within the 2e-2 gradient tolerance of the bf16 path, no longer bit-near to one rank);
@@ -60,6 +69,9 @@ class DataParallelExecutor:
         if big_transport not in ('fp32', 'bf16') or big_algo not in ('all_reduce', 'reduce_scatter'):
             raise ValueError('big_transport must be fp32 or bf16, big_algo all_reduce or reduce_scatter')
         self.big_transport, self.big_algo = big_transport, big_algo
+        self.shard_big_update = bool(shard_big_update)
+        self._shard_bufs = {}        # name -> persistent fp32 buffer of this rank's slice of the gradient
+        self._sharded = {}           # name -> that buffer, for gradients reduce-scattered this step
         self._big_bufs = {}          # name -> persistent (bf16 staging, shard) buffers
         self._big_after = []         # (fp32 gradient, bf16 staging) to cast back once the collectives are done
         self.net = net
@@ -91,6 +103,7 @@ class DataParallelExecutor:
         net.grad_group_hook = self._on_group
         net.plan_ready_hook = self._on_plan
         self._aux, self._presence_host, self._presence_event, self._presence_launched = None, None, None, False
+        self._keep_big = None
         net.backward_done_hook = self._on_backward_done
         self._avg = dist.get_backend(process_group) == 'nccl'
 
@@ -168,9 +181,28 @@ class DataParallelExecutor:
         w.wait()       # RCCL: the current stream waits, the host does not; the all-gather reads the slice
         self._works.append(dist.all_gather_into_tensor(src, shard, group=self.pg, async_op=True))
 
+    def _shardable(self, name, grad):
+        """Only the executor's first linear layer, whose update vqa_amd.optim.FusedAdam can run on a
+        slice of rows."""
+        net = self.net
+        idx = getattr(net, '_fc_idx', None)
+        return (self.shard_big_update and idx is not None and
+                name == 'classifier.%d.weight' % idx[0] and grad.dim() == 2 and grad.shape[0] % self.world == 0 and
+                grad.dtype == torch.float32)
+
     def _on_grad(self, name, grad):
         self._pending = True
         if grad.numel() * grad.element_size() >= self.direct_bytes and grad.is_contiguous():
+            if self._shardable(name, grad):
+                n = grad.numel() // self.world
+                shard = self._shard_bufs.get(name)
+                if shard is None or shard.numel() != n or shard.device != grad.device:
+                    shard = self._shard_bufs[name] = torch.empty(n, dtype=torch.float32, device=grad.device)
+                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+                self._works.append(dist.reduce_scatter_tensor(shard, grad.view(-1), op=op, group=self.pg, async_op=True))
+                self._sharded[name] = shard
+                self._keep_big = grad            # read by the collective until finish_grad_sync() has waited
+                return
             self._direct[name] = grad
             self._reduce_big(name, grad)     # in place, overlapped with the rest of backward
         else:
@@ -273,6 +305,14 @@ class DataParallelExecutor:
         for n, p in self._params:
             if n in self._grouped_names:
                 continue
+            if n in self._sharded:
+                # this rank's rows of the averaged gradient, for FusedAdam's update of the same rows
+                shard = self._sharded[n]
+                if not self._avg:
+                    shard.mul_(scale)
+                p.grad = None
+                self.net._fc1_grad_shard = (shard, self.rank, self.world, self)
+                continue
             if n in self._direct:
                 g = self._direct[n]
                 if not self._avg:
@@ -288,14 +328,43 @@ class DataParallelExecutor:
             off, cnt = self._layout[n]
             p.grad = self._flat[off:off + cnt].view(p.shape)
         self._direct, self._small, self._presence, self._pending = {}, {}, None, False
+        self._sharded, self._keep_big = {}, None
         self._groups, self._small_groups = [], []
         self._presence_launched = False
+
+    # ---------------------------------------------------------------- sharded update of the first linear layer
+    def gather_big_packed(self, packed):
+        """Called by FusedAdam after it updated this rank's rows: every rank's rows of the bf16 copy
+        [rows][...] are exchanged.  Not waited for here: the executor waits before its next use of
+        that copy (ModuleNet._wait_fc1_gather), with the stem and the module tree in between."""
+        flat = packed.view(-1)
+        n = flat.numel() // self.world
+        piece = flat[self.rank * n:(self.rank + 1) * n]
+        self.net._fc1_gather = dist.all_gather_into_tensor(flat, piece, group=self.pg, async_op=True)
+        self.net._fc1_master_stale = True
+
+    def gather_sharded_state(self, optimizer=None):
+        """All ranks: bring the fp32 master copy of the sharded layer (and, given the optimizer, its
+        Adam moments) up to date everywhere - before state_dict(), a checkpoint, or any other reader."""
+        net = self.net
+        if not getattr(net, '_fc1_master_stale', False):
+            return
+        p = net.classifier[net._fc_idx[0]].weight
+        tensors = [p.data]
+        if optimizer is not None and p in optimizer.state:
+            tensors += [optimizer.state[p]['exp_avg'], optimizer.state[p]['exp_avg_sq']]
+        for t in tensors:
+            flat = t.view(-1)
+            n = flat.numel() // self.world
+            dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n].clone(), group=self.pg)
+        net._fc1_master_stale = False
 
     # convenience passthroughs
     def parameters(self):
         return self.net.parameters()
 
     def state_dict(self):
+        self.gather_sharded_state()
         return self.net.state_dict()
 
     def train(self, mode=True):

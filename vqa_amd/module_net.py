@@ -230,6 +230,12 @@ class ModuleNet(nn.Module):
         self._fc1_packed = None       # persistent bf16 copy of the first linear layer's weight
         self.segment_marks = None     # diagnostics: see _mark
         self._fc1_fresh = False       # set by vqa_amd.optim.FusedAdam: that copy already holds the updated weight
+        # set by vqa_amd.dp.DataParallelExecutor(shard_big_update=True): this rank's rows of the first
+        # linear layer's averaged gradient; the all-gather of the updated bf16 rows still in flight;
+        # whether the fp32 master copy is current on its owning ranks only
+        self._fc1_grad_shard = None
+        self._fc1_gather = None
+        self._fc1_master_stale = False
         self.used_fns = None
         self.wgrad_chunk = 32
         # module width 128: both convolutions of a residual body run in one kernel; False selects
@@ -380,6 +386,10 @@ class ModuleNet(nn.Module):
                 if li == 0:
                     buf = self._fc1_packed_buffer(device)
                     if not fc1_ready:
+                        if self._fc1_master_stale:
+                            raise RuntimeError('the first linear layer is updated in slices (shard_big_update): call '
+                                               'DataParallelExecutor.gather_sharded_state() on every rank before '
+                                               'changing parameters in any other way')
                         ops.fc_weight_to_nhwc(lin.weight.contiguous(), buf, fo, _rup(fo, 128), p_)
                 else:
                     buf = self._packed.get('fc_w', [None] * (li + 1))[li] if self._packed_key is not None else None
@@ -790,6 +800,7 @@ class ModuleNet(nn.Module):
         acts = [c1]
         prev_dim = HW * p_
         fcs = list(d['fcs']) + [d['na']]
+        self._wait_fc1_gather()       # the first linear layer's bf16 copy is read from here on
         for li, fo in enumerate(fcs):
             lin = self.classifier[self._fc_idx[li]]
             last = li == len(fcs) - 1
@@ -854,6 +865,14 @@ class ModuleNet(nn.Module):
             raise KeyError('program token id outside the vocabulary')
         if flags & 2:
             raise IndexError('image_index out of range')
+
+    def _wait_fc1_gather(self):
+        """The current stream waits for the exchange of the first linear layer's updated bf16 rows
+        (DataParallelExecutor.gather_big_packed) if one is in flight."""
+        w = self._fc1_gather
+        if w is not None:
+            w.wait()
+            self._fc1_gather = None
 
     def _params_changed(self):
         """Parameters are about to change without their version counters moving (a backward pass is

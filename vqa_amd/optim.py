@@ -100,6 +100,11 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad
                 tgt = targets.get(p.data_ptr()) if targets is not None else None
                 managed += tgt is not None
+                shard = None
+                if g is None and p is fc1 and getattr(ex, '_fc1_grad_shard', None) is not None:
+                    # data parallel with shard_big_update: this rank holds, and updates, its rows only
+                    shard, ex._fc1_grad_shard = ex._fc1_grad_shard, None
+                    g = shard[0]
                 if g is None:
                     continue          # unused token this step: no update, no step count (as torch)
                 if g.dtype != f32 or g.is_sparse:
@@ -124,9 +129,21 @@ class FusedAdam(torch.optim.Optimizer):
                 if p is fc1:
                     packed = ex._fc1_packed_buffer(p.device)
                     F, P = p.shape[0], ex._dims['p']
-                    _lib.check(lib.vqa_adam_fc1(p.data_ptr(), g.data_ptr(), r[4], r[5], packed.data_ptr(), F, P,
-                                                wd, b1, b2, eps, sc[0], sc[1],
-                                                torch.cuda.current_stream(p.device).cuda_stream))
+                    stream = torch.cuda.current_stream(p.device).cuda_stream
+                    if shard is None:
+                        _lib.check(lib.vqa_adam_fc1(p.data_ptr(), g.data_ptr(), r[4], r[5], packed.data_ptr(), F, P,
+                                                    wd, b1, b2, eps, sc[0], sc[1], stream))
+                    else:
+                        _, rank, world, dp = shard
+                        if packed.shape[0] != F:
+                            raise RuntimeError('a sharded update needs the layer\'s output width to be a multiple of 128')
+                        ex._wait_fc1_gather()      # the previous step's exchange writes the same buffer
+                        rows = F // world
+                        off = rank * rows * p.shape[1]          # elements in front of this rank's rows
+                        _lib.check(lib.vqa_adam_fc1(p.data_ptr() + 4 * off, g.data_ptr(), r[4] + 4 * off, r[5] + 4 * off,
+                                                    packed.data_ptr() + 2 * off, rows, P,
+                                                    wd, b1, b2, eps, sc[0], sc[1], stream))
+                        dp.gather_big_packed(packed)
                     ex._fc1_fresh = True
                     keep.append(g)
                     continue
