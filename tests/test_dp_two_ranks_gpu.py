@@ -61,6 +61,9 @@ def _train(rank, world, out_path, big=('fp32', 'all_reduce'), shard=False):
         opt.step()
         losses.append(float(loss.detach()))
     if world > 1:
+        if shard:
+            with pytest.raises(RuntimeError, match='gather_sharded_state'):
+                net.state_dict()                 # the fp32 copy is stale outside this rank's rows: refused
         step_net.gather_sharded_state(opt)       # (nothing to do unless the update was sharded)
     torch.cuda.synchronize()
     res = (losses, first_grads, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()},

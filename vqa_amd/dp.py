@@ -104,6 +104,7 @@ class DataParallelExecutor:
         net.plan_ready_hook = self._on_plan
         self._aux, self._presence_host, self._presence_event, self._presence_launched = None, None, None, False
         self._keep_big = None
+        self._moments_stale = False
         net.backward_done_hook = self._on_backward_done
         self._avg = dist.get_backend(process_group) == 'nccl'
 
@@ -341,23 +342,26 @@ class DataParallelExecutor:
         n = flat.numel() // self.world
         piece = flat[self.rank * n:(self.rank + 1) * n]
         self.net._fc1_gather = dist.all_gather_into_tensor(flat, piece, group=self.pg, async_op=True)
-        self.net._fc1_master_stale = True
+        self.net._fc1_master_stale = self._moments_stale = True
 
     def gather_sharded_state(self, optimizer=None):
         """All ranks: bring the fp32 master copy of the sharded layer (and, given the optimizer, its
         Adam moments) up to date everywhere - before state_dict(), a checkpoint, or any other reader."""
         net = self.net
-        if not getattr(net, '_fc1_master_stale', False):
-            return
-        p = net.classifier[net._fc_idx[0]].weight
-        tensors = [p.data]
-        if optimizer is not None and p in optimizer.state:
-            tensors += [optimizer.state[p]['exp_avg'], optimizer.state[p]['exp_avg_sq']]
+        tensors = []
+        if getattr(net, '_fc1_master_stale', False):
+            p = net.classifier[net._fc_idx[0]].weight
+            tensors.append(p.data)
+            net._fc1_master_stale = False
+        if optimizer is not None and self._moments_stale:
+            p = net.classifier[net._fc_idx[0]].weight
+            if p in optimizer.state:
+                tensors += [optimizer.state[p]['exp_avg'], optimizer.state[p]['exp_avg_sq']]
+            self._moments_stale = False
         for t in tensors:
             flat = t.view(-1)
             n = flat.numel() // self.world
             dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n].clone(), group=self.pg)
-        net._fc1_master_stale = False
 
     # convenience passthroughs
     def parameters(self):

@@ -866,6 +866,13 @@ class ModuleNet(nn.Module):
         if flags & 2:
             raise IndexError('image_index out of range')
 
+    def state_dict(self, *args, **kwargs):
+        if self._fc1_master_stale:
+            raise RuntimeError('the first linear layer is updated in slices (DataParallelExecutor(shard_big_update=True)): '
+                               'its fp32 copy is current on the owning ranks only - call gather_sharded_state() on '
+                               'every rank (the wrapper\'s state_dict() does) before reading the state')
+        return super().state_dict(*args, **kwargs)
+
     def _wait_fc1_gather(self):
         """The current stream waits for the exchange of the first linear layer's updated bf16 rows
         (DataParallelExecutor.gather_big_packed) if one is in flight."""
