@@ -112,24 +112,26 @@ def test_two_ranks_match_whole_batch_training(big):
         assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (r0[0], whole[0])
 
 
-def test_two_ranks_with_the_first_linear_layer_updated_in_slices():
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_with_the_first_linear_layer_updated_in_slices(world):
     """shard_big_update: the first linear layer's gradient is reduce-scattered by rows, each rank runs
     Adam on its rows and the updated bf16 rows are all-gathered under the next forward.  The losses
-    follow whole-batch training, both ranks end with the same parameters and Adam moments once the
+    follow whole-batch training, all ranks end with the same parameters and Adam moments once the
     master copy is gathered, and those equal the replicated update's to fp32 rounding."""
     import torch.multiprocessing as mp
     runs = {}
     for shard in (False, True):
         s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
         with tempfile.TemporaryDirectory() as d:
-            mp.spawn(_rank_main, args=(2, port, d, ('fp32', 'all_reduce'), shard), nprocs=2, join=True)
-            runs[shard] = [torch.load(os.path.join(d, 'rank%d.pt' % r), weights_only=True) for r in (0, 1)]
-    r0, r1 = runs[True]
-    for k in r0[2]:
-        assert torch.equal(r0[2][k], r1[2][k]), k
-    for k in r0[3]:
-        assert torch.equal(r0[3][k], r1[3][k]), k
-    assert r0[0] == r1[0]
+            mp.spawn(_rank_main, args=(world, port, d, ('fp32', 'all_reduce'), shard), nprocs=world, join=True)
+            runs[shard] = [torch.load(os.path.join(d, 'rank%d.pt' % r), weights_only=True) for r in range(world)]
+    r0 = runs[True][0]
+    for r1 in runs[True][1:]:
+        for k in r0[2]:
+            assert torch.equal(r0[2][k], r1[2][k]), k
+        for k in r0[3]:
+            assert torch.equal(r0[3][k], r1[3][k]), k
+        assert r0[0] == r1[0]
     assert r0[1]['classifier.3.weight'] is None            # the gradient lives as per-rank rows
     rep = runs[False][0]
     for a, b in zip(r0[0], rep[0]):
