@@ -35,3 +35,25 @@ def test_one_json_line_with_the_agreed_keys():
     assert d['mfma_peak_frac'] <= d['model_flops_frac']      # executed work never exceeds the reference-equivalent count
     fb = d['executor_fwd_bwd']                                # the executor alone, beside the whole-step headline
     assert 0 < fb['ms_per_step'] and fb['mfma_peak_frac'] > 0 and 'not the headline' in fb['note']
+
+
+def test_two_rank_launch_path_rehearsed_on_one_gpu():
+    """The script's multi-rank path as the driver launches it (torch.distributed.run, one process per
+    rank, RANK/LOCAL_RANK/WORLD_SIZE from the environment): both ranks on this box's one GPU with the
+    collectives staged through the host (VQA_BENCH_REHEARSE_SHARED_GPU; the figures mean nothing).
+    One JSON line from rank 0, whole-job values, the sharded update of the first linear layer named."""
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, VQA_BENCH_REHEARSE_SHARED_GPU='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '64', '--batches', '1'],
+                       capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['global_batch'] == 128
+    assert abs(d['value'] - 128 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+    assert 'sharded over the ranks' in d['config']['parallelism'] and 'rehearsal' in d
+    assert 'cpu_baseline' not in d and 'executor_fwd_bwd' not in d          # rank 0 at N = 1 only
