@@ -127,6 +127,8 @@ enum {
     VQA_SEC_WG_PITEMS, VQA_SEC_WG_PSRC0, VQA_SEC_WG_PSRC1, VQA_SEC_WG_PDY,
     VQA_SEC_SAMPLE_ITEMS_FINE, /* as SAMPLE_ITEMS in chunks of max(1, min(wgrad_chunk, N/128)) samples */
     VQA_SEC_SLOTS_SCDZ, VQA_SEC_SLOTS_SCY, /* per sample: dZ slot of its scene node that runs; that node's output slot */
+    VQA_SEC_SCENE_DPROJ_TILES, /* conv tiles, fused path only: dP(binary node) -> dZ of those of its inputs that
+                                  are scene nodes (the other destination is -1), masks = their outputs */
     VQA_SEC_COUNT
 };
 int vqa_plan_section(const vqa_plan* plan, int32_t id, int32_t* offset, int32_t* count);
@@ -182,45 +184,54 @@ int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps /* 9 or 1 */, void* st
  * (Layers.py:33-36 / Module_Model.py:38-40,47-50 forward; their input gradients backward).  All
  * maps are slots of one arena, 256-byte pixels.
  *   [pre, if src1 >= 0:  slot res = [relu](pre([src0; src1]) + bias_pre), and the input is that map;
+ *    pre, if pre_group >= 0:  slot res = pre_half(src0) * (pre_mask > 0), likewise the input, where
+ *      pre_half is outputs [128 h, 128 h + 128) of 1x1 weight group g, pre_group = 2 g + h, K = 128;
  *    otherwise the input is src0]
  *   slot dst1 = [relu](first(input) + bias_first) * (mask1 > 0)
  *   slot dst0 = [relu](second(dst1 map) + bias_second + res) * (mask0 > 0)
- *   [post, if post_dst0 >= 0:  (post_dst0, post_dst1) = post(dst0 map) * (post_mask0 > 0, post_mask1 > 0)]
- * Forward of a ConcatBlock uses pre (the 1x1 projection of the concatenated children); its backward
- * uses post (the transposed projection, one half of its 256 outputs per child). */
+ * Forward of a ConcatBlock uses the first form (the 1x1 projection of the concatenated children,
+ * Module_Model.py:38-39).  Backward, a ConcatBlock's tile ends with dP in dst0 and each of its two
+ * children starts with the second form: its half of the transposed projection of the parent's dP,
+ * masked by its own output, which is its dZ. */
 typedef struct {
     int32_t src0, src1;
     int32_t dst0, dst1;
     int32_t res;                /* -1: none */
     int32_t mask0, mask1;       /* -1: none */
     int32_t wgroup;             /* weight group (token id) */
-    int32_t post_dst0, post_dst1, post_mask0, post_mask1;
+    int32_t pre_group;          /* -1: none; else 2 * (weight group of w_pre) + output half */
+    int32_t pre_mask;           /* -1: none */
+    int32_t reserved0, reserved1;
 } vqa_resblock_tile;
 
 typedef struct {
     void* arena;
     const void* w_first;        /* packed 3x3 weights of the first convolution, one group per token */
     const void* w_second;
-    const void* w_pre;          /* packed 1x1 weights, K = 256 (two sources), 128 outputs; or null */
-    const void* w_post;         /* packed 1x1 weights, K = 128, 256 outputs; or null */
+    const void* w_pre;          /* packed 1x1 weights: K = 256 (two sources), 128 outputs for tiles with
+                                   src1 >= 0; K = 128, 256 outputs for tiles with pre_group >= 0; or null */
+    const void* w_unused;       /* keeps the layout of earlier versions; ignored */
     const float* bias_first;    /* fp32 [groups][128] or null */
     const float* bias_second;
     const float* bias_pre;
     const vqa_resblock_tile* tiles; /* device */
     int64_t slot_stride;        /* elements between slots (196 * 128) */
     int64_t w_group_stride;     /* elements between 3x3 weight groups (9 * 128 * 128) */
-    int64_t w_pre_group_stride; /* elements between 1x1 weight groups (2 * 128 * 128), pre and post */
-    int32_t flags;              /* VQA_CONV_BIAS | VQA_CONV_RELU, applied to every convolution but post */
+    int64_t w_pre_group_stride; /* elements between 1x1 weight groups (2 * 128 * 128) */
+    int32_t flags;              /* VQA_CONV_BIAS | VQA_CONV_RELU, applied to every convolution but the
+                                   pre_group form of pre */
     int32_t num_tiles;
-    int32_t num_pre, num_post;  /* how many tiles have a pre / post part (work accounting and
-                                   argument checks; the kernel decides per tile) */
+    int32_t num_pre;            /* how many K = 256 1x1 passes the tiles hold in front (two pre_group
+                                   tiles count as one; work accounting and argument checks: the
+                                   kernel decides per tile) */
+    int32_t unused0;
     unsigned long long* phase_stamps; /* diagnostics: null, or device [num_tiles][8] shader-clock
                                    timestamps of each tile's phase boundaries */
     const int32_t* level_info;  /* null, or device {first tile, tiles}: the tile range is read on the
                                    device (`tiles` + first tile, that many) and shared by the
                                    num_tiles workgroups of the launch, whatever its length; for tile
                                    lists made by vqa_devsched_build, whose sizes the host never
-                                   learns.  num_pre / num_post then only say whether such tiles may
+                                   learns.  num_pre then only says whether such tiles may
                                    occur */
 } vqa_resblock_params;
 

@@ -1,5 +1,5 @@
 """Fused node kernel, shader-clock phases of binary nodes against unary ones: forward (the 1x1
-projection ahead of the body) and backward (the transposed projection behind it, one pass per child)."""
+projection ahead of the body) and backward (a child's half of the transposed projection ahead of its body)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,8 +18,8 @@ for T in (256, 512):
         'forward binary': ([[i, 5 * T + i, 2 * T + i, T + i, 6 * T + i, -1, -1, i % 4, -1, -1, -1, -1] for i in range(T)],
                            dict(w_pre=pre, num_pre=T)),
         'backward unary': ([[i, -1, 2 * T + i, T + i, i, 3 * T + i, 4 * T + i, i % 4, -1, -1, -1, -1] for i in range(T)], {}),
-        'backward binary': ([[i, -1, 2 * T + i, T + i, i, 3 * T + i, 4 * T + i, i % 4, 7 * T + i, 8 * T + i, 5 * T + i, 6 * T + i]
-                             for i in range(T)], dict(w_post=post, num_post=T)),
+        'backward child of binary': ([[9 * T + i, -1, 2 * T + i, T + i, i, 3 * T + i, 4 * T + i, i % 4, 2 * ((i + 1) % 4) + i % 2, 5 * T + i, 0, 0]
+                                      for i in range(T)], dict(w_pre=post, num_pre=T // 2)),
     }
     for name, (rows, kw) in kinds.items():
         tiles = torch.tensor(rows, dtype=torch.int32).reshape(-1).to(d)
@@ -31,9 +31,9 @@ for T in (256, 512):
         ops.resblock_tiles(arena, p1, p1, tiles, T, relu=name.startswith('forward'), phase_stamps=stamps, **kw)
         e1.record(); torch.cuda.synchronize()
         s = stamps.cpu().double()
-        last = 7 if 'backward binary' == name else 6
+        last = 6
         ph = s[:, 1:last + 1] - s[:, 0:last]
         names = ['stage', 'pre', 'K1', 'epi1', 'K2', 'epi2', 'post'][:last]
-        print('T=%d %-16s wall %5.1f us | ' % (T, name, e0.elapsed_time(e1) * 1e3) +
+        print('T=%d %-24s wall %5.1f us | ' % (T, name, e0.elapsed_time(e1) * 1e3) +
               ' '.join('%s %.0f' % (n, ph[:, i].median().item()) for i, n in enumerate(names)) +
               ' | total %.0f' % (s[:, last] - s[:, 0]).median().item())

@@ -180,9 +180,9 @@ def test_resblock_fused_matches_two_launches_and_torch(backward):
 
 
 def test_resblock_fused_with_projection_pre_and_post():
-    """Binary nodes: the fused kernel also runs the 1x1 projection of the two children in front
-    (forward) and the transposed projection behind (backward); compared bit for bit with the
-    separate launches."""
+    """Binary nodes: the fused kernel also runs the 1x1 projection of the two children in front of the
+    node's body (forward) and, backward, each child's half of the transposed projection in front of
+    the child's body; compared bit for bit with the separate launches."""
     from vqa_amd import ops
     C, G, S = 128, 2, 5
     x0, x1 = bf(F.relu(rnd((S, C, 14, 14), 51))), bf(F.relu(rnd((S, C, 14, 14), 52)))
@@ -216,26 +216,52 @@ def test_resblock_fused_with_projection_pre_and_post():
     ref_p = torch.stack([F.relu(F.conv2d(torch.cat([x0[i:i + 1], x1[i:i + 1]], 1), wp[groups[i]], bp[groups[i]]))[0] for i in range(S)])
     close(P, ref_p)
     assert from_slots(arena[4 * S:5 * S], C).abs().max() > 0
-    # ---- backward.  slots: dZ | H | P | x0 | x1 | dH dP dx0 dx1 (fused) | dH dP dx0 dx1 (separate)
-    dz = bf(rnd((S, C, 14, 14), 59))
-    hm = bf(F.relu(rnd((S, C, 14, 14), 60)))
-    arena = torch.cat([to_slots(dz), to_slots(hm), to_slots(ref_p), to_slots(x0), to_slots(x1), zeros(8)])
+    # ---- backward.  A binary node's tile ends with dP; each of its two inputs starts its own tile with
+    # its half of the transposed projection of that dP, masked by its own output (its dZ), and runs its
+    # body on it.  slots: dP | Y0 Y1 (the inputs' outputs) | H0 H1 | X0 X1 (masks of the inputs' bodies) |
+    # fused: dZ0 dZ1 dH0 dH1 dX0 dX1 | separate: dZ0 dZ1 dH0 dH1 dX0 dX1
+    dpar = bf(rnd((S, C, 14, 14), 59))
+    hm = [bf(F.relu(rnd((S, C, 14, 14), 60 + c))) for c in range(2)]
+    xm = [bf(F.relu(rnd((S, C, 14, 14), 62 + c))) for c in range(2)]
+    arena = torch.cat([to_slots(dpar), to_slots(x0), to_slots(x1), to_slots(hm[0]), to_slots(hm[1]),
+                       to_slots(xm[0]), to_slots(xm[1]), zeros(12)])
     d1 = ops.pack_conv_weight(w1.to(d), G, C, C, 9, C * C * 9, 9, C * 9, flip=True)
     d2 = ops.pack_conv_weight(w2.to(d), G, C, C, 9, C * C * 9, 9, C * 9, flip=True)
     dp = ops.pack_conv_weight(wp.to(d), G, 2 * C, C, 1, 2 * C * C, 1, 2 * C)
-    fused = tiles_tensor([[i, -1, 6 * S + i, 5 * S + i, i, 2 * S + i, S + i, groups[i],
-                           7 * S + i, 8 * S + i, 3 * S + i, 4 * S + i] for i in range(S)])
-    ops.resblock_tiles(arena, d2, d1, fused, S, w_post=dp, num_post=S)
-    t_g2 = tiles_tensor([[i, -1, 9 * S + i, -1, -1, S + i, -1, groups[i]] for i in range(S)])
-    t_g1 = tiles_tensor([[9 * S + i, -1, 10 * S + i, -1, i, 2 * S + i, -1, groups[i]] for i in range(S)])
-    t_dp = tiles_tensor([[10 * S + i, -1, 11 * S + i, 12 * S + i, -1, 3 * S + i, 4 * S + i, groups[i]] for i in range(S)])
-    ops.conv_tiles(arena, arena, d2, t_g2, S, taps=9, w_group_stride=9 * C * C, mask=arena, **geo)
-    ops.conv_tiles(arena, arena, d1, t_g1, S, taps=9, w_group_stride=9 * C * C, res=arena, mask=arena, **geo)
+    own = lambda i, c: (i + c) % G          # the inputs' own tokens differ from their parent's
+    base = 7 * S
+    fused = tiles_tensor([[i, -1, base + (4 + c) * S + i, base + (2 + c) * S + i, base + c * S + i, (5 + c) * S + i,
+                           (3 + c) * S + i, own(i, c), 2 * groups[i] + c, (1 + c) * S + i, 0, 0]
+                          for c in range(2) for i in range(S)])
+    ops.resblock_tiles(arena, d2, d1, fused, 2 * S, w_pre=dp, num_pre=S)
+    sep = base + 6 * S
+    t_dp = tiles_tensor([[i, -1, sep + i, sep + S + i, -1, S + i, 2 * S + i, groups[i]] for i in range(S)])
+    t_g2 = tiles_tensor([[sep + c * S + i, -1, sep + (2 + c) * S + i, -1, -1, (3 + c) * S + i, -1, own(i, c)]
+                         for c in range(2) for i in range(S)])
+    t_g1 = tiles_tensor([[sep + (2 + c) * S + i, -1, sep + (4 + c) * S + i, -1, sep + c * S + i, (5 + c) * S + i, -1, own(i, c)]
+                         for c in range(2) for i in range(S)])
     ops.conv_tiles(arena, arena, dp, t_dp, S, taps=1, w_group_stride=2 * C * C, mask=arena, pair_out=1,
                    **dict(geo, n_out=2 * C))
+    ops.conv_tiles(arena, arena, d2, t_g2, 2 * S, taps=9, w_group_stride=9 * C * C, mask=arena, **geo)
+    ops.conv_tiles(arena, arena, d1, t_g1, 2 * S, taps=9, w_group_stride=9 * C * C, res=arena, mask=arena, **geo)
     torch.cuda.synchronize()
-    assert torch.equal(arena[5 * S:9 * S], arena[9 * S:13 * S])
-    assert from_slots(arena[7 * S:9 * S], C).abs().max() > 0
+    assert torch.equal(arena[base:base + 6 * S], arena[sep:sep + 6 * S])
+    full = F.conv_transpose2d(dpar, wp[0]) if G == 1 else torch.stack(
+        [F.conv_transpose2d(dpar[i:i + 1], wp[groups[i]])[0] for i in range(S)])
+    close(from_slots(arena[base:base + S], C), full[:, :C] * (x0 > 0))
+    close(from_slots(arena[base + S:base + 2 * S], C), full[:, C:] * (x1 > 0))
+    assert from_slots(arena[base + 4 * S:base + 6 * S], C).abs().max() > 0
+    # a destination nobody wants (the scene inputs' launch has one per tile at most): left alone
+    arena[sep:sep + 2 * S] = 7
+    t_half = tiles_tensor([[i, -1, -1 if i % 2 else sep + i, sep + S + i if i % 2 else -1, -1, S + i, 2 * S + i, groups[i]]
+                           for i in range(S)])
+    ops.conv_tiles(arena, arena, dp, t_half, S, taps=1, w_group_stride=2 * C * C, mask=arena, pair_out=1,
+                   **dict(geo, n_out=2 * C))
+    torch.cuda.synchronize()
+    for i in range(S):
+        keep, written = (sep + i, sep + S + i) if i % 2 else (sep + S + i, sep + i)
+        assert (arena[keep] == 7).all()
+        assert torch.equal(arena[written], arena[base + (written - sep)])
 
 
 def test_conv1x1_dgrad_pair_out():

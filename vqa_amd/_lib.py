@@ -54,10 +54,10 @@ class TreeCtx(C.Structure):
 
 
 class ResblockParams(C.Structure):
-    _fields_ = [('arena', vp), ('w_first', vp), ('w_second', vp), ('w_pre', vp), ('w_post', vp),
+    _fields_ = [('arena', vp), ('w_first', vp), ('w_second', vp), ('w_pre', vp), ('w_unused', vp),
                 ('bias_first', vp), ('bias_second', vp), ('bias_pre', vp), ('tiles', vp),
                 ('slot_stride', i64), ('w_group_stride', i64), ('w_pre_group_stride', i64),
-                ('flags', i32), ('num_tiles', i32), ('num_pre', i32), ('num_post', i32),
+                ('flags', i32), ('num_tiles', i32), ('num_pre', i32), ('unused0', i32),
                 ('phase_stamps', vp), ('level_info', vp)]
 
 
@@ -71,7 +71,8 @@ SEC = {name: i for i, name in enumerate((
     'STEM0_TILES', 'STEM1_TILES', 'STEM1_DGRAD_TILES', 'CLS_FWD_TILES', 'CLS_DGRAD_TILES',
     'SLOTS_IDENT', 'SLOTS_S0', 'SLOTS_F', 'SLOTS_DF', 'SLOTS_DS0', 'SLOTS_ROOTY', 'SAMPLE_ITEMS',
     'SCENE_OFFSETS', 'SCENE_SRC', 'WG_ITEMS', 'WG_SRC_C1', 'WG_DY_C1', 'WG_SRC_C2', 'WG_DY_C2',
-    'WG_PITEMS', 'WG_PSRC0', 'WG_PSRC1', 'WG_PDY', 'SAMPLE_ITEMS_FINE', 'SLOTS_SCDZ', 'SLOTS_SCY'))}
+    'WG_PITEMS', 'WG_PSRC0', 'WG_PSRC1', 'WG_PDY', 'SAMPLE_ITEMS_FINE', 'SLOTS_SCDZ', 'SLOTS_SCY',
+    'SCENE_DPROJ_TILES'))}
 
 CONV_BIAS, CONV_RELU = 1, 2
 TREE_UNFUSED, TREE_F32, TREE_SKIP_LEVEL0 = 1, 2, 4

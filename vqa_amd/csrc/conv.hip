@@ -218,6 +218,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
     const int l15 = lane & 15, lq = lane >> 4;
     const vqa_conv_tile t = p.tiles[xcd_tile_index(blockIdx.x, p.num_tiles)];
     const int ntile = blockIdx.y;
+    // an output half nobody wants (pair outputs with one destination missing): uniform over the workgroup
+    if (p.pair_out > 0 && ((ntile / p.pair_out) ? t.dst1 : t.dst0) < 0) return;
 
     // this wave's weight stream: K-step s (32 channels of one tap) is two adjacent 1 KiB blocks
     const int64_t wstep = (int64_t)(p.n_out / 16) * 1024;
@@ -278,8 +280,11 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 // Fused module body (module width 128 only): every convolution of one tree node in one workgroup.
 //   forward :  [P = relu(proj([x0; x1]) + bp)]   H = relu(conv1(x) + b1);   Y = relu(x + conv2(H) + b2)
 //              (Layers.py:33-36, Module_Model.py:38-40,47-50; x = P for a binary node)
-//   backward:  dH = dgrad2(dZ) * (H > 0);   dX = (dgrad1(dH) + dZ) * (X > 0);
-//              [binary: (dx0, dx1) = dproj(dX) * (x0 > 0, x1 > 0)]
+//   backward:  [child of a binary node: dZ = dproj_half(dP of the parent) * (Y > 0)]
+//              dH = dgrad2(dZ) * (H > 0);   dX = (dgrad1(dH) + dZ) * (X > 0)
+//              (a binary node's dX is its dP; each child takes its half of the transposed projection
+//              in front of its own body, as forward takes the projection in front of the parent's:
+//              no tile is two passes longer than the others of its launch)
 // No intermediate map makes a round trip: accumulators are rounded to bf16 straight into the halo
 // image that the next convolution reads, and leave for HBM (they are needed again by the backward
 // pass / the weight gradients) as whole 256-byte rows from that image.  One launch per tree level,
@@ -376,11 +381,20 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     const int64_t wstep = 8 * 1024;                 // 128 output channels: 8 fragments of 1 KiB per K-step
     const int64_t wlane = (int64_t)(wave * 2) * 1024 + lane * 16;
     const int64_t w33 = (int64_t)t.wgroup * p.w_group_stride * 2 + wlane;
-    const bool pre = t.src1 >= 0;
-    const char* wbase = pre ? (const char*)p.w_pre + (int64_t)t.wgroup * p.w_pre_group_stride * 2 + wlane
-                            : (const char*)p.w_first + w33;
+    // A 1x1 pass in front of the body.  Forward (src1 >= 0): the node's own projection of its two
+    // inputs, K = 256, 8 fragments per K-step.  Backward (pre_group >= 0): this node's half of its
+    // PARENT's transposed projection, K = 128 over the parent's dP map; the pack holds both halves
+    // (16 fragments per K-step), half h starting 8 fragments in.
+    const bool pre2 = t.src1 >= 0, pre1 = t.pre_group >= 0;
+    int64_t wstep_pre = wstep;
+    const char* wbase = (const char*)p.w_first + w33;
+    if (pre2) wbase = (const char*)p.w_pre + (int64_t)t.wgroup * p.w_pre_group_stride * 2 + wlane;
+    else if (pre1) {
+        wbase = (const char*)p.w_pre + (int64_t)(t.pre_group >> 1) * p.w_pre_group_stride * 2 + (t.pre_group & 1) * wstep + wlane;
+        wstep_pre = 2 * wstep;
+    }
     bf16x8 wr[4][2];
-    load_wring(wr, wbase, wstep);
+    load_wring(wr, wbase, wstep_pre);
     halo_zero_border(halo, tid);
     f32x4 acc[MT][2];
     int xaddr[MT];
@@ -391,18 +405,24 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     __syncthreads();
     STAMP(1);
     int s = 0;
-    if (pre) {   // binary node: x = relu(proj([src0; src1]) + bias_pre), kept in slot `res`
+    if (pre2 || pre1) {   // x = [relu](pre(sources) + bias_pre) * (pre_mask > 0), kept in slot `res`
         // (cleared registers here, not the zero-first form: with it the register allocator spills)
 #pragma unroll
         for (int m = 0; m < MT; m++) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        conv_kloop<1, false>(halo, xaddr, wbase, wstep, 8, s, wr, acc, false);
-        __syncthreads();
-        halo_stage(halo, arena + (int64_t)t.src1 * slot_b, 256, tid, false);
-        __syncthreads();
-        conv_kloop<1, false>(halo, xaddr, wbase, wstep, 8, s, wr, acc, false);
+        const int nsteps_pre = pre2 ? 8 : 4;
+#pragma unroll 1
+        for (int c = 0; c < (pre2 ? 2 : 1); c++) {
+            if (c) {
+                __syncthreads();
+                halo_stage(halo, arena + (int64_t)t.src1 * slot_b, 256, tid, false);
+                __syncthreads();
+            }
+            conv_kloop<1, false>(halo, xaddr, wbase, wstep_pre, nsteps_pre, s, wr, acc, false);
+        }
         wbase = (const char*)p.w_first + w33;
         load_wring(wr, wbase, wstep);
-        acc_to_image(halo, acc, has_bias ? p.bias_pre + (int64_t)t.wgroup * 128 : nullptr, relu, nullptr,
+        acc_to_image(halo, acc, (pre2 && has_bias) ? p.bias_pre + (int64_t)t.wgroup * 128 : nullptr, pre2 && relu,
+                     t.pre_mask >= 0 ? arena + (int64_t)t.pre_mask * slot_b : nullptr,
                      arena + (int64_t)t.res * slot_b, tid);
         s = 0;
     }
@@ -421,34 +441,10 @@ __global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_par
     conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
     STAMP(5);
 
-    const bool post = t.post_dst0 >= 0;
-    char* d0 = arena + (int64_t)t.dst0 * slot_b;
     conv_epilogue(halo, acc, has_bias ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr, relu,
                   t.res >= 0 ? arena + (int64_t)t.res * slot_b : nullptr,
-                  t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, d0, 128, tid);
+                  t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, 128, tid);
     STAMP(6);
-    if (post) {
-
-    // binary node, backward: the map just stored (dP) goes through the transposed 1x1 projection,
-    // 256 outputs = one pass per child; the epilogue staging destroys the image, so it is staged
-    // again for the second pass (a 50 KB read that hits in L2)
-#pragma unroll 1
-    for (int child = 0; child < 2; child++) {
-        wbase = (const char*)p.w_post + (int64_t)t.wgroup * p.w_pre_group_stride * 2 + wlane + child * 8 * 1024;
-        load_wring(wr, wbase, 2 * wstep);
-        __syncthreads();     // the epilogue's stores are issued and its staging reads are done
-        halo_stage(halo, d0, 256, tid, false);
-        __syncthreads();
-        s = 0;
-        conv_kloop<1, true>(halo, xaddr, wbase, 2 * wstep, 4, s, wr, acc, false);
-        const int dslot = child ? t.post_dst1 : t.post_dst0, mslot = child ? t.post_mask1 : t.post_mask0;
-        // no bias and no residual are added here, so rounding the accumulators straight into the
-        // image and masking in the row pass gives the same bits as the fp32-staged epilogue, cheaper
-        acc_to_image(halo, acc, nullptr, false, mslot >= 0 ? arena + (int64_t)mslot * slot_b : nullptr,
-                     arena + (int64_t)dslot * slot_b, tid);
-    }
-    STAMP(7);
-    }
     if (RANGE) __syncthreads();     // the next tile's staging overwrites the image this one's epilogue reads
     } while (RANGE && (tile_i += (int)gridDim.x) < tile_end);
 #undef STAMP
@@ -479,17 +475,17 @@ extern "C" int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps, void* stre
 extern "C" int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream) {
     if (!p || !p->arena || !p->w_first || !p->w_second || !p->tiles || p->num_tiles < 0 ||
         ((p->flags & VQA_CONV_BIAS) && (!p->bias_first || !p->bias_second)) ||
-        (p->num_pre > 0 && (!p->w_pre || ((p->flags & VQA_CONV_BIAS) && !p->bias_pre))) ||
-        (p->num_post > 0 && !p->w_post)) {
+        (p->num_pre > 0 && (!p->w_pre || ((p->flags & VQA_CONV_BIAS) && !p->bias_pre)))) {
         vqa_set_error("vqa_resblock_tiles: bad argument");
         return VQA_EINVAL;
     }
     if (p->num_tiles == 0) return VQA_OK;
     if (!vqa_allow_lds((const void*)resblock_tiles_kernel<false>, CONV_LDS, "vqa_resblock_tiles") ||
         !vqa_allow_lds((const void*)resblock_tiles_kernel<true>, CONV_LDS, "vqa_resblock_tiles")) return VQA_ELAUNCH;
-    // two 3x3 convolutions of 128 -> 128 channels per tile, plus the 1x1 projection of binary nodes
+    // two 3x3 convolutions of 128 -> 128 channels per tile, plus the 1x1 passes in front: K = 256 per
+    // forward binary node, K = 128 per backward child of one (num_pre counts K = 256 equivalents)
     VqaProfScope prof(VQA_K_RESBLOCK, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles +
-                                          2.0 * VQA_HW * 256.0 * 128.0 * (p->num_pre + p->num_post),
+                                          2.0 * VQA_HW * 256.0 * 128.0 * p->num_pre,
                       (double)p->num_tiles * VQA_HW * 2.0 * 128 * 3, (hipStream_t)stream);
     if (p->level_info) hipLaunchKernelGGL(resblock_tiles_kernel<true>, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(resblock_tiles_kernel<false>, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);

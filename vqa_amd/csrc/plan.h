@@ -11,6 +11,7 @@ struct PlanNode { int32_t sample, token, col, child0, child1, level; };
 
 struct PlanLevel {
     int count = 0, bcount = 0;
+    int half_count = 0;   // backward tiles of the level that start with a half of their parent's transposed projection
     int off_proj = 0, off_conv1 = 0, off_conv2 = 0, off_dgrad2 = 0, off_dgrad1 = 0, off_dproj = 0;
     int off_fused_fwd = 0, off_fused_bwd = 0;   // residual body as one tile (vqa_resblock_tiles)
 };

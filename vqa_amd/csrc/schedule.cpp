@@ -239,6 +239,9 @@ void build_backward_part(vqa_plan* pl) {
     const int N = pl->N, NV = (int)pl->nodes.size(), V = pl->V, wgrad_chunk = pl->wgrad_chunk;
     const int scene_id = pl->scene_id;
     pl->finished = true;
+    std::vector<int> parent(NV, -1);     // plans with a backward part share no nodes: one user each
+    for (int v = 0; v < NV; v++)
+        for (int c : {pl->nodes[v].child0, pl->nodes[v].child1}) if (c >= 0) parent[c] = v;
     for (int L = 0; L < pl->num_levels; L++) {
         PlanLevel& lv = pl->levels[L];
         const std::vector<int>& nodes = pl->level_nodes[L];
@@ -269,16 +272,23 @@ void build_backward_part(vqa_plan* pl) {
                           pl->slot_dZ + nd.child1, -1, y_slot(pl, nd.child0), y_slot(pl, nd.child1), nd.token);
             }
         }
-        if (pl->has_fused) {   // dZ -> dH -> dX [-> children's dZ] as one tile
+        if (pl->has_fused) {   // [dP of the parent -> dZ] -> dH -> dX as one tile
+            // A binary node's dX is its dP; each input of it that is not a scene node takes its half of
+            // the transposed projection in front of its own body (pre_group = 2 * parent token + half,
+            // masked by its own output), so src0 is the parent's dP and the dZ slot is written, not read.
             lv.off_fused_bwd = (int)b.size();
+            lv.half_count = 0;
             for (int v : nodes) {
                 const PlanNode& nd = pl->nodes[v];
                 int dst, mask;
                 target(v, dst, mask);
-                const bool bin = nd.child1 >= 0;
-                const int32_t w[12] = {pl->slot_dZ + v, -1, dst, dh_slot(pl, v), pl->slot_dZ + v, mask, h_slot(pl, v),
-                                       nd.token, bin ? pl->slot_dZ + nd.child0 : -1, bin ? pl->slot_dZ + nd.child1 : -1,
-                                       bin ? y_slot(pl, nd.child0) : -1, bin ? y_slot(pl, nd.child1) : -1};
+                const int par = nd.token == scene_id ? -1 : parent[v];
+                const bool half = par >= 0 && pl->nodes[par].child1 >= 0;
+                lv.half_count += half;
+                const int32_t w[12] = {half ? pl->slot_dP + pl->bin_index[par] : pl->slot_dZ + v, -1, dst, dh_slot(pl, v),
+                                       pl->slot_dZ + v, mask, h_slot(pl, v), nd.token,
+                                       half ? 2 * pl->nodes[par].token + (pl->nodes[par].child1 == v) : -1,
+                                       half ? y_slot(pl, v) : -1, 0, 0};
                 b.insert(b.end(), w, w + 12);
             }
         }
@@ -294,6 +304,24 @@ void build_backward_part(vqa_plan* pl) {
     for (int i = 0; i < N; i++)
         push_tile(b, i, -1, pl->slot_dZ + pl->roots[i], -1, -1, y_slot(pl, pl->roots[i]), -1, 0);
     endsec(VQA_SEC_CLS_DGRAD_TILES, N);
+    // Scene inputs of binary nodes: a scene node runs once per image for all of its users, so nobody's
+    // tile can take the projection half in front; one 1x1 launch ahead of the scene level does it for
+    // every such pair of the batch.
+    sec(VQA_SEC_SCENE_DPROJ_TILES);
+    int npairs = 0;
+    if (pl->has_fused) {
+        for (int v = 0; v < NV; v++) {
+            const PlanNode& nd = pl->nodes[v];
+            if (nd.child1 < 0) continue;
+            const bool s0 = pl->nodes[nd.child0].token == scene_id, s1 = pl->nodes[nd.child1].token == scene_id;
+            if (!s0 && !s1) continue;
+            push_tile(b, pl->slot_dP + pl->bin_index[v], -1, s0 ? pl->slot_dZ + nd.child0 : -1,
+                      s1 ? pl->slot_dZ + nd.child1 : -1, -1, s0 ? y_slot(pl, nd.child0) : -1,
+                      s1 ? y_slot(pl, nd.child1) : -1, nd.token);
+            npairs++;
+        }
+    }
+    endsec(VQA_SEC_SCENE_DPROJ_TILES, npairs);
 
     auto slot_list = [&](int id, int base_slot) {
         sec(id);
@@ -591,7 +619,7 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     pl->has_separate = !(flags & VQA_PLAN_SKIP_SEPARATE);
     pl->has_fused = !(flags & VQA_PLAN_SKIP_FUSED);
     // upper bound of the finished blob, so that a caller can size its buffers after the forward part
-    pl->blob_bound = (size_t)NV * 80 + (size_t)N * 64 + (size_t)nb * 24 + (size_t)V * 16 + 1024;
+    pl->blob_bound = (size_t)NV * 80 + (size_t)N * 64 + (size_t)nb * 32 + (size_t)V * 16 + 1024;
     pl->blob.reserve(pl->blob_bound);
     build_forward_part(pl);
     pl->fwd_words = (int)pl->blob.size();

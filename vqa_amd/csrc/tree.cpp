@@ -111,9 +111,19 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     for (int L = pl->num_levels - 1; L >= 0; L--) {
         const PlanLevel& lv = pl->levels[L];
         if (L == 0) {
+            const int32_t* bl = c->blob;
+            if (fused && pl->sec_cnt[VQA_SEC_SCENE_DPROJ_TILES] > 0) {
+                // binary nodes' dP -> the dZ of their inputs that are scene nodes (every other input
+                // takes its half of the transposed projection inside its own tile)
+                vqa_conv_params p = base_conv(pl, c);
+                p.w = c->wd_proj; p.w_group_stride = w11;
+                p.tiles = tiles_at(c, pl->sec_off[VQA_SEC_SCENE_DPROJ_TILES]);
+                p.num_tiles = pl->sec_cnt[VQA_SEC_SCENE_DPROJ_TILES];
+                p.n_out = 2 * pl->C; p.pair_out = cc;
+                if ((rc = vqa_conv_tiles(&p, 1, stream))) return rc;
+            }
             // every scene node of a sample is the same computation, run once: the gradients that its
             // users wrote for each of them are summed into the one that ran, times (its output > 0)
-            const int32_t* bl = c->blob;
             rc = f32 ? vqa_slot_sum_mask_f32((float*)c->arena, bl + pl->sec_off[VQA_SEC_SCENE_OFFSETS],
                                              bl + pl->sec_off[VQA_SEC_SCENE_SRC], bl + pl->sec_off[VQA_SEC_SLOTS_SCDZ],
                                              bl + pl->sec_off[VQA_SEC_SLOTS_SCY], pl->N, slot, stream)
@@ -125,9 +135,9 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
         if (fused) {
             vqa_resblock_params p = {};
             p.arena = c->arena;
-            p.w_first = c->wd_conv2; p.w_second = c->wd_conv1; p.w_post = c->wd_proj;
+            p.w_first = c->wd_conv2; p.w_second = c->wd_conv1; p.w_pre = c->wd_proj;
             p.tiles = (const vqa_resblock_tile*)(c->blob + lv.off_fused_bwd); p.num_tiles = lv.count;
-            p.num_post = lv.bcount;
+            p.num_pre = lv.half_count / 2;
             p.slot_stride = slot; p.w_group_stride = w33; p.w_pre_group_stride = w11;
             if ((rc = vqa_resblock_tiles(&p, stream))) return rc;
             continue;

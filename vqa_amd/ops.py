@@ -50,7 +50,7 @@ def conv_tiles(src, dst, w_packed, tiles, num_tiles, *, taps, k_chunks, n_out, s
 
 
 def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=None, bias_second=None,
-                   relu=False, tiles_offset=0, w_pre=None, bias_pre=None, w_post=None, num_pre=0, num_post=0,
+                   relu=False, tiles_offset=0, w_pre=None, bias_pre=None, num_pre=0,
                    phase_stamps=None, level_info=None, level=0):
     """Every convolution of a 128-wide tree node, one workgroup per tile (vqa_resblock_tiles);
     `arena` is bf16 [slots][196][128], `tiles` holds 12-word vqa_resblock_tile records.  With
@@ -60,14 +60,13 @@ def resblock_tiles(arena, w_first, w_second, tiles, num_tiles, *, bias_first=Non
     p = _lib.ResblockParams()
     p.arena, p.w_first, p.w_second = arena.data_ptr(), w_first.data_ptr(), w_second.data_ptr()
     p.w_pre = w_pre.data_ptr() if w_pre is not None else 0
-    p.w_post = w_post.data_ptr() if w_post is not None else 0
     p.bias_first = bias_first.data_ptr() if bias_first is not None else 0
     p.bias_second = bias_second.data_ptr() if bias_second is not None else 0
     p.bias_pre = bias_pre.data_ptr() if bias_pre is not None else 0
     p.tiles = tiles.data_ptr() + 4 * tiles_offset
     p.slot_stride, p.w_group_stride, p.w_pre_group_stride = 196 * 128, 9 * 128 * 128, 2 * 128 * 128
     p.flags = (_lib.CONV_BIAS if bias_first is not None else 0) | (_lib.CONV_RELU if relu else 0)
-    p.num_tiles, p.num_pre, p.num_post = num_tiles, num_pre, num_post
+    p.num_tiles, p.num_pre = num_tiles, num_pre
     p.phase_stamps = phase_stamps.data_ptr() if phase_stamps is not None else 0
     p.level_info = level_info.data_ptr() + 8 * level if level_info is not None else 0
     _lib.check(_lib.load().vqa_resblock_tiles(C.byref(p), _stream()))
