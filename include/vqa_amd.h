@@ -254,7 +254,7 @@ int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream);
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     const int64_t* programs;  /* device [N][T] token ids */
-    const int8_t* arity;      /* device [V]; 0 for the scene token only */
+    const int8_t* arity;      /* device [V]; 1 or 2 for every token but scene (checked per row read, see error) */
     float* used;              /* device out [N][T]: Module_Model.py:227,231 used_fns */
     int32_t* node;            /* device workspace [N][2T+1][4], 16-byte aligned */
     int32_t* counts;          /* device workspace [N][4], 16-byte aligned */
@@ -266,7 +266,8 @@ typedef struct {
     int32_t* tiles;           /* device out [N*T][12]: vqa_resblock_tile records, level-major; 16-byte aligned */
     int32_t* cls_tiles;       /* device out [N][8]: vqa_conv_tile records of the classifier's gather; 16-byte aligned */
     int32_t* error;           /* device out [2]: flags (1: a token id outside [0, V); 2: an image index
-                                 outside [0, num_images)); the deepest root's level */
+                                 outside [0, num_images); 4: a token other than scene whose arity is not 1
+                                 or 2 - such a row runs as a lone scene too); the deepest root's level */
     const int32_t* image_of_row; /* null: row i runs on image i.  Else device [N]: the image of each row
                                  (candidate scoring, Train_model.py:339-347: K programs on one image):
                                  stem and scene module run once per image, the rows of an image all read

@@ -1,12 +1,17 @@
-"""The scheduler on the device (vqa_devsched_build) against the host scheduler, which the CPU tests pin
-to the oracle's restatement of forward_modules_ints_helper (Module_Model.py:196-222) and to the hook
-traces of the reference: the same trees per row, the same earliest levels, the same used_fns, and,
-through the executor, the same logits bit for bit - on well-formed programs, on an untrained
+"""The scheduler on the device (vqa_devsched_build) against three checkers: the oracle's restatement
+of forward_modules_ints_helper (Module_Model.py:196-222), row by row; the hook traces captured from
+the reference itself (tests/golden/schedule_quirks.json), case by case; and the host scheduler
+(levels, histogram, slots).  The same trees per row, the same earliest levels, the same used_fns,
+and, through the executor, the same logits bit for bit - on well-formed programs, on an untrained
 sampler's rows (LSTM_Model.py:205-235) and on every quirk row."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
+from oracle.module_net_ref import parse_row
 from vqa_amd import synth
 from vqa_amd import vocab as V
 from vqa_amd.schedule import Plan
@@ -45,13 +50,32 @@ def device_schedule(prog, vocab, spread=False):
     return sched, used.cpu().numpy()
 
 
-def check_against_host(prog, vocab, spread=False):
-    """Rebuild every row's tree from the device's tile records and compare with the host plan's.
+def oracle_trees(prog, vocab):
+    """Per row, from the oracle's interpreter: the tree as nested (token id, inputs...) tuples and the
+    row of used_fns."""
+    t2i, i2t = vocab['program_token_to_idx'], vocab['program_idx_to_token']
+    trees, used = [], []
+    for row in prog:
+        nodes, u = parse_row(row, i2t)
+
+        def nest(v):
+            return (t2i[nodes[v][0]],) + tuple(nest(c) for c in nodes[v][2])
+        trees.append(nest(len(nodes) - 1))
+        used.append(u)
+    return trees, np.asarray(used, dtype=np.float32)
+
+
+def check_against_host(prog, vocab, spread=False, want_trees=None, want_used=None):
+    """Rebuild every row's tree from the device's tile records and compare it with the oracle's parse
+    of the row (or with `want_trees`, the reference's own trace) and with the host plan's.
     Levels: the host's earliest ones without `spread`; with it, any levels in which inputs run
     before their users, no more of them than the deepest program needs."""
     scene = vocab['program_token_to_idx']['scene']
     N, T = prog.shape
     sched, used = device_schedule(prog, vocab, spread)
+    if want_trees is None:
+        want_trees, want_used = oracle_trees(prog, vocab)
+    np.testing.assert_array_equal(used, want_used)
     plan = Plan(prog, vocab)
     nodes, roots = plan.nodes(), plan.roots()
     np.testing.assert_array_equal(used, plan.used_fns())
@@ -109,8 +133,33 @@ def check_against_host(prog, vocab, spread=False):
     np.testing.assert_array_equal(cls[:, 2], np.arange(N))
     assert (cls[:, [1, 3, 4, 5, 6]] == -1).all() and (cls[:, 7] == 0).all()
     for i in range(N):
-        assert dev_tree(int(cls[i, 0]), i)[0] == host_tree(roots[i]), i
+        got = dev_tree(int(cls[i, 0]), i)[0]
+        assert got == want_trees[i], i
+        assert got == host_tree(roots[i]), i
     return hist.sum(1), want_hist.sum(1)
+
+
+@pytest.mark.parametrize('spread', [False, True])
+def test_reference_hook_traces(vocab, golden_dir, spread):
+    """Every case of the fixture captured from the reference executor with forward hooks (execution
+    order, inputs, used_fns; T = 12 and T = 30 rows): the device's trees and used_fns are the
+    reference's."""
+    with open(os.path.join(golden_dir, 'schedule_quirks.json')) as f:
+        cases = json.load(f)['cases']
+    by_T = {}
+    for c in cases:
+        by_T.setdefault(c['T'], []).append(c)
+    assert len(by_T) >= 2
+    for T, cs in sorted(by_T.items()):
+        trees = []
+        for c in cs:
+            def nest(v, c=c):
+                return (c['tokens'][v],) + tuple(nest(k) for k in c['children'][v] if k >= 0)
+            trees.append(nest(len(c['tokens']) - 1))
+        prog = np.array([c['program'] for c in cs], dtype=np.int64)
+        assert prog.shape == (len(cs), T)
+        check_against_host(prog, vocab, spread, want_trees=trees,
+                           want_used=np.array([c['used_fns'] for c in cs], dtype=np.float32))
 
 
 @pytest.mark.parametrize('spread', [False, True])
@@ -144,6 +193,37 @@ def test_token_outside_the_vocabulary_raises_the_flag(vocab):
     li = sched.level_info.cpu().numpy().reshape(-1, 2)
     want = np.bincount(plan.nodes()[plan.nodes()[:, 1] != t2i['scene'], 5], minlength=len(li))
     np.testing.assert_array_equal(li[:, 1], want)
+
+
+def test_arity_table_the_node_records_cannot_hold_raises_the_flag(vocab):
+    """A device arity table with 0 (or 3) for a token other than scene: rows that read that token set
+    bit 2 of the flags and run as a lone scene module; the others are scheduled as ever."""
+    from vqa_amd import ops
+    t2i = vocab['program_token_to_idx']
+    prog = synth.synth_programs(8, 12, vocab, max_len=12, max_nodes=9)
+    prog[3, :3] = [t2i['count'], t2i['exist'], t2i['scene']]
+    prog[[0, 1, 2] + list(range(4, 12))] = np.where(prog[[0, 1, 2] + list(range(4, 12))] == t2i['exist'], t2i['count'],
+                                                     prog[[0, 1, 2] + list(range(4, 12))])
+    for wrong in (0, 3):
+        ar = np.asarray(V.arity_table(vocab), dtype=np.int8)
+        ar[t2i['exist']] = wrong
+        N, T = prog.shape
+        buf = torch.full((ops.DeviceSchedule.words(N, T, len(ar)),), -7, dtype=torch.int32, device='cuda')
+        sched = ops.DeviceSchedule(buf, N, T, len(ar))
+        used = torch.full((N, T), -1.0, device='cuda')
+        ops.devsched_build(torch.from_numpy(prog).cuda(), torch.from_numpy(ar).cuda(), used, sched, t2i['<NULL>'],
+                           t2i['<START>'], t2i['scene'])
+        torch.cuda.synchronize()
+        assert int(sched.error[0].item()) == 4
+        assert (used[3] == 0).all()
+        good = prog.copy()
+        good[3] = t2i['<NULL>']
+        good[3, 0] = t2i['scene']
+        plan = Plan(good, vocab)
+        li = sched.level_info.cpu().numpy().reshape(-1, 2)
+        want = np.bincount(plan.nodes()[plan.nodes()[:, 1] != t2i['scene'], 5], minlength=len(li))
+        np.testing.assert_array_equal(li[:, 1], want)
+        np.testing.assert_array_equal(np.delete(used.cpu().numpy(), 3, 0), np.delete(plan.used_fns(), 3, 0))
 
 
 @pytest.mark.parametrize('balance', [False, True])      # of the host's levels and of the device's

@@ -130,8 +130,8 @@ def test_fused_and_two_launch_residual_body_identical(vocab):
         out.append((logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
     assert torch.equal(out[0][0], out[1][0])
     assert out[0][1].keys() == out[1][1].keys()
-    # bias gradients are accumulated with fp32 atomics (order varies run to run) and the weight gradients'
-    # partial blocks group differently on the two paths: tight, not bitwise
+    # the partial blocks of the weight and bias gradients group differently on the two paths (the sums are
+    # the same up to fp32 summation order): tight, not bitwise
     for k in out[0][1]:
         assert rel(out[0][1][k], out[1][1][k]) <= 1e-5, k
 

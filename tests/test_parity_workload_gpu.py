@@ -128,8 +128,8 @@ def test_bench_batch_fused_balanced_equals_two_launch_unbalanced(vocab):
     """The production configuration (fused node kernel, balanced levels) against the plain one (two
     launches per residual body, earliest levels) on the benchmark's batch with the dense upstream
     gradient of the training loss: same logits bit for bit, same gradients (weight gradients are
-    sums of partial blocks whose grouping follows the launch a node runs in, bias gradients fp32
-    atomics: equal to fp32 summation order)."""
+    and bias gradients are sums of partial blocks whose grouping follows the launch a node runs in:
+    equal to fp32 summation order)."""
     from vqa_amd.module_net import ModuleNet
     n, seed = 1024, 3100
     prog, x, ans = _bench_batch(vocab, n, seed)
@@ -273,6 +273,95 @@ def test_score_candidates_on_sampler_and_quirk_rows(vocab):
         rl_ = ref(x[img], pt)
     assert rel(shared, rl_) <= TOL, rel(shared, rl_)
     assert torch.equal(used, ref.used_fns)
+
+
+def test_score_candidates_default_model_64_images_x_8_candidates(vocab):
+    """BASELINE's rollout-scoring configuration at full size: the default 117 M-parameter model, 64
+    images, K = 8 rows of an untrained sampler per image (T = 30, mostly ill-formed: implicit scenes,
+    <NULL>/<END> run as modules), one score_candidates call (Train_model.py:339-347).  16 rows spread
+    over the images against the fp32 oracle on those rows alone (2e-2), the reference's used_fns for
+    all 512 rows, and the interning scheduler's logits against the plain expanded batch bit for bit."""
+    from vqa_amd.module_net import ModuleNet
+    M, K, T = 64, 8, 30
+    t2i, i2t = vocab['program_token_to_idx'], vocab['program_idx_to_token']
+    prog = synth.synth_sampler_programs(4000, M * K, len(t2i), T)
+    prog[5 * K + 3] = prog[5 * K]                       # identical candidates of one image
+    prog[9 * K:10 * K, 20:] = prog[9 * K, 20:]          # candidates that share a tail
+    img = torch.arange(M).repeat_interleave(K)
+    g = torch.Generator(device='cuda').manual_seed(4000)
+    x = torch.randn(M, 1024, 14, 14, device='cuda', generator=g).clamp_(min=0)
+    sd = synth.synth_state_dict(17, vocab)
+    net = ModuleNet(False, vocab)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    pt = torch.from_numpy(prog).cuda()
+    with torch.no_grad():
+        shared = net.score_candidates(x, pt, img).clone()
+        used = net.used_fns.cpu().numpy().copy()
+        full = net(x[img.cuda()], pt)
+    torch.cuda.synchronize()
+    assert torch.equal(shared, full)
+    want_used = np.array([parse_row(r.tolist(), i2t)[1] for r in prog], dtype=np.float32)
+    np.testing.assert_array_equal(used, want_used)
+    rows = sorted(set([0, 5 * K, 5 * K + 3, 9 * K + 1, M * K - 1] + list(range(11, M * K, 47))))[:16]
+    rt = torch.as_tensor(rows)
+    with torch.no_grad():
+        l32 = ModuleNetRef(vocab, sd)(x[img[rt].cuda()].cpu(), torch.from_numpy(prog[rows]))
+    assert rel(shared[rt.cuda()], l32) <= TOL, rel(shared[rt.cuda()], l32)
+    # and the executor's choice among an image's candidates (Train_model.py:346-347) is the oracle's
+    # wherever the oracle's own margin is not within the tolerance
+    top2 = l32.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * TOL * l32.abs().max()
+    assert torch.equal(shared[rt.cuda()].argmax(1).cpu()[clear], l32.argmax(1)[clear])
+
+
+def test_deep_program_stress_batch_512_rows_match_the_oracle(vocab):
+    """BASELINE's deep-program stress at full size, the batch `bench.py --config 5` builds: module
+    width 256, 512 programs of up to 60 nodes in 64 columns, the default stem, classifier projection
+    and 1024-unit linear layer.  Logits and used_fns of 8 rows against the fp32 oracle on those rows;
+    with an upstream gradient supported on those rows, every gradient against the bf16-storage oracle
+    at the HIP path's own activations (2e-2)."""
+    from vqa_amd.module_net import ModuleNet
+    n, seed = 512, 3000
+    prog = synth.synth_programs(seed, n, vocab, max_len=64, max_nodes=60)
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = torch.randn(n, 1024, 14, 14, device='cuda', generator=g).clamp_(min=0)
+    ans = torch.from_numpy(synth.synth_answers(seed, n))
+    depth = (prog != 0).sum(1)
+    assert depth.max() >= 45
+    rows = sorted(set([0, n - 1, int(depth.argmax()), int(depth.argmin())] + list(range(29, n, 71))))[:8]
+    sd = synth.synth_state_dict(17, vocab, module_dim=256)
+    net = ModuleNet(False, vocab, module_dim=256)
+    net.load_state_dict(sd)
+    net.cuda().train()
+    net.keep_state = True
+    logits = net(x, torch.from_numpy(prog).cuda())
+    st = net.last_state
+    rt = torch.as_tensor(rows)
+    xs, ps, as_ = x[rt.cuda()].cpu(), torch.from_numpy(prog[rows]), ans[rt]
+    with torch.no_grad():
+        l32 = ModuleNetRef(vocab, sd)(xs, ps)
+    assert rel(logits[rt.cuda()], l32) <= TOL, 'logits rel err %g' % rel(logits[rt.cuda()], l32)
+    i2t = vocab['program_idx_to_token']
+    used = np.array([parse_row(r.tolist(), i2t)[1] for r in prog], dtype=np.float32)
+    np.testing.assert_array_equal(net.used_fns.cpu().numpy(), used)
+    up_rows = _ce_grad(l32, as_)
+    up = torch.zeros(n, l32.size(1))
+    up[rt] = up_rows
+    logits.backward(up.cuda())
+    torch.cuda.synchronize()
+    ref = ModuleNetRef(vocab, sd, storage='bf16', forced=subset_forcer(net, st, rows))
+    ref(xs, ps).backward(up_rows)
+    rg = ref.grads()
+    worst = ('', 0.0)
+    for k, p in net.named_parameters():
+        if rg[k] is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        e = rel(p.grad, rg[k])
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] <= TOL, 'gradient rel err %g on %s' % (worst[1], worst[0])
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp32'])

@@ -1,8 +1,10 @@
 """vqa_wgrad_tiles_noalloc (partial blocks in the library's static device array, no allocation)
 against the existing pair vqa_wgrad_tiles(partial workspace) + vqa_wgrad_reduce, through the C ABI.
 
-Same kernels on the same inputs, so the weight gradients must be bit-identical; the bias gradient is
-accumulated with fp32 atomics on both sides (order varies): 1e-6.  Two calls in a row, the second on
+Same kernels on the same inputs, so the weight gradients must be bit-identical.  Neither call here
+asks for rows of bias sums behind the partial blocks (the training path does, and sums them in item
+order), so on both sides the bias gradient takes the kernel's other form, fp32 atomics whose order
+varies: 1e-6.  Two calls in a row, the second on
 a smaller input (the array keeps the first call's contents), then a single-tap call, then a
 request beyond the array's size, which must be refused with a message."""
 import numpy as np

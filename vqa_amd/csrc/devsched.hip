@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void devsched_parse_kernel(vqa_devsched_params 
     __syncthreads();
     if (row < p.N) {
         int j = 0, n = 0, np = 0, sp = 0, root = 0;
-        bool bad = false;
+        bool bad = false, bad_arity = false;
         for (;;) {
             int tok;
             for (;;) {
@@ -70,6 +70,9 @@ __global__ __launch_bounds__(64) void devsched_parse_kernel(vqa_devsched_params 
             }
             if (bad) break;
             const int ar = tok == p.scene_id ? 0 : arity[tok];
+            // a table that gives a module other than scene no input, or more than two: the node records
+            // (two inputs, leaves are scene outputs) cannot hold that row
+            if (tok != p.scene_id && (ar < 1 || ar > 2)) { bad = bad_arity = true; break; }
             if (ar == 0) {
                 int id = n++;
                 int lvl = 0;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(64) void devsched_parse_kernel(vqa_devsched_params 
             }
         }
         if (bad) {
-            atomicOr(p.error, 1);
+            atomicOr(p.error, bad_arity ? 4 : 1);
             for (int c = 0; c < T; c++) toks[c * B + t] = 0;
             n = 1; root = 0;
             node[t] = p.scene_id; node[B + t] = -1; node[2 * B + t] = -1;

@@ -263,6 +263,9 @@ class ModuleNet(nn.Module):
         self.schedule_on_device = False
         self.device_spread_levels = True     # rows with slack run later by differing shares of it: evener launches
         self.device_level_workgroups = 512     # two per CU: all resident at once
+        # which of the two weight gradients that feed nothing else in backward run on the side stream
+        # (A: the first linear layer's; B: that, then the classifier convolution's; C: only the latter)
+        self.backward_order = os.environ.get('VQA_BWD_ORDER', 'A')
         self.schedule_error = None
         self._arity_dev = None
         self.keep_state = False       # tests: keep the last call's buffers in self.last_state
@@ -865,6 +868,8 @@ class ModuleNet(nn.Module):
             raise KeyError('program token id outside the vocabulary')
         if flags & 2:
             raise IndexError('image_index out of range')
+        if flags & 4:
+            raise ValueError('the arity table gives a module other than scene no input or more than two')
 
     def state_dict(self, *args, **kwargs):
         if self._fc1_master_stale:
@@ -1211,19 +1216,11 @@ class ModuleNet(nn.Module):
                 act_t = ws.get('fc0_act_t', np128 * fi, torch.bfloat16, dev)
 
                 def fc1_weight_grad(g=g, g_ld=g_ld, gw=gw, li=li, name=name):
-                    cur, side = torch.cuda.current_stream(dev), self._side
-                    fork = torch.cuda.Event()
-                    fork.record(cur)
-                    with torch.cuda.stream(side):
-                        side.wait_event(fork)
-                        ops.transpose_hw_c(acts[li], act_t, np128, p_)
-                        ops.gemm(g, act_t, gw, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
-                        if self.grad_ready_hook is not None:
-                            self.grad_ready_hook(name + '.weight', gw)
-                            emitted.add(name + '.weight')
-                        done = torch.cuda.Event()
-                        done.record(side)
-                    return done
+                    ops.transpose_hw_c(acts[li], act_t, np128, p_)
+                    ops.gemm(g, act_t, gw, fo, fi, np64, lda=g_ld, ldb=fi, ldc=fi, a_kmajor=True, b_kmajor=True)
+                    if self.grad_ready_hook is not None:
+                        self.grad_ready_hook(name + '.weight', gw)
+                        emitted.add(name + '.weight')
             grads[name + '.weight'] = gw
             # input gradient, masked by the ReLU that produced the input
             gin = ws.get('fc_gin%d' % li, np128 * fi, torch.bfloat16, dev)
@@ -1233,10 +1230,6 @@ class ModuleNet(nn.Module):
             ops.gemm(g, pk['fc_w'][li], gin, N, fi, kdim, lda=g_ld, ldb=fi, ldc=fi, b_kmajor=True,
                      out_bf16=True, mask=acts[li])
             g, g_ld = gin, fi
-            if li == 0:
-                # behind the input-gradient GEMM: two device-filling GEMMs side by side only slow
-                # each other down
-                side_done = fc1_weight_grad()
             if li > 0:
                 gb = torch.zeros(fi, **f32)
                 ops.col_sum(gin, gb, N, fi, fi)
@@ -1244,24 +1237,48 @@ class ModuleNet(nn.Module):
         dc1 = g   # bf16 [N][196][P], already times (C1 > 0)
         self._mark('fc_bwd')
 
-        # ---- classifier conv1x1: weight/bias gradient, then gradient into the roots' dZ slots
+        # ---- classifier conv1x1: weight/bias gradient, and the gradient into the roots' dZ slots
         it_off, it_cnt = plan.section('SAMPLE_ITEMS')
         sec = lambda n: (blob, plan.section(n)[0])
         gcb = torch.zeros(p_, **f32)
         info = plan.info
         # partial blocks of the largest launch, with one row of bias sums per item behind them: every
         # gradient is summed in item order, the same bits on every run
-        need_blocks = max(info.wgrad_partial_blocks, sum(ops.wgrad_blocks(it_cnt, p_, c // 128, 1)),
-                          sum(ops.wgrad_blocks(it_cnt, c, cpad // 128, 9)),
+        need_blocks = max(info.wgrad_partial_blocks, sum(ops.wgrad_blocks(it_cnt, c, cpad // 128, 9)),
                           sum(ops.wgrad_blocks(plan.section('SAMPLE_ITEMS_FINE')[1], c, c // 128, 9)))
         part = ws.get('wg_partial', need_blocks * 8192, torch.float32, dev)
-        ops.wgrad_tiles(arena, dc1, (blob, it_off), it_cnt, sec('SLOTS_ROOTY'), sec('SLOTS_IDENT'), None, gcb,
-                        taps=1, k_chunks=c // 128, n_out=p_, src_slot_stride=HW * c, dy_slot_stride=HW * p_,
-                        src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_, total_nodes=N, partial=part,
-                        bias_rows=True)
-        gw = torch.empty(p_, c, 1, 1, **f32)
-        ops.wgrad_reduce(part, (blob, it_off), it_cnt, 1, p_, c // 128, 1, gw, 0, db=gcb)
-        grads['classifier.0.weight'], grads['classifier.0.bias'] = gw, gcb
+        # (a buffer of its own: this one launch runs beside the tree's, on the side stream)
+        part_cls = ws.get('wg_partial_cls', sum(ops.wgrad_blocks(it_cnt, p_, c // 128, 1)) * 8192, torch.float32, dev)
+        gw_cls = torch.empty(p_, c, 1, 1, **f32)
+        grads['classifier.0.weight'], grads['classifier.0.bias'] = gw_cls, gcb
+
+        def cls_weight_grad():
+            ops.wgrad_tiles(arena, dc1, (blob, it_off), it_cnt, sec('SLOTS_ROOTY'), sec('SLOTS_IDENT'), None, gcb,
+                            taps=1, k_chunks=c // 128, n_out=p_, src_slot_stride=HW * c, dy_slot_stride=HW * p_,
+                            src_pix_stride=c, dy_pix_stride=p_, dw_group_stride=c * p_, total_nodes=N, partial=part_cls,
+                            bias_rows=True)
+            ops.wgrad_reduce(part_cls, (blob, it_off), it_cnt, 1, p_, c // 128, 1, gw_cls, 0, db=gcb)
+
+        # Two weight gradients feed nothing else in this pass: the first linear layer's (most of the
+        # network's parameters; two device-filling GEMMs side by side only slow each other down, so
+        # it starts behind the input-gradient GEMM) and the classifier convolution's (bound by HBM,
+        # not by the matrix cores).  What the tree needs is the gradient into the roots.
+        order = self.backward_order
+        cur, side = torch.cuda.current_stream(dev), self._side
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            if order in ('A', 'B'):
+                fc1_weight_grad()
+            if order in ('B', 'C'):
+                cls_weight_grad()
+            side_done = torch.cuda.Event()
+            side_done.record(side)
+        if order == 'C':
+            fc1_weight_grad()
+        if order == 'A':
+            cls_weight_grad()
         self._conv(st, dc1, arena, pk['wd_cls'], 'CLS_DGRAD_TILES', 1, p_ // 128, c, (HW * p_, p_), slot,
                    mask=arena)
 
