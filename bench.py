@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the module-executor train step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one process per GPU: either launched by torch.distributed.run (WORLD_SIZE etc. in the
+environment), or started plainly as above, in which case this process - before it touches a GPU -
+starts torch.distributed.run on itself as a child, relays the child's result line and exit code.
 
 One step = one pass of the hot path over one synthetic CLEVR-shape batch per GPU: features
 NCHW fp32 -> executor forward -> cross-entropy -> executor backward -> gradient all-reduce (N > 1)
@@ -43,9 +47,11 @@ def parse():
     ap.add_argument('--max-nodes', type=int, default=None)
     ap.add_argument('--batches', type=int, default=4, help='distinct resident synthetic batches cycled through')
     ap.add_argument('--no-optimizer', action='store_true')
-    ap.add_argument('--dp-replicated-update', action='store_true',
-                    help="N > 1: every rank all-reduces the first linear layer's gradient and updates the whole layer; default: "
-                         'reduce-scatter by rows, each rank updates its rows, the updated bf16 rows are all-gathered (same arithmetic)')
+    ap.add_argument('--dp-sharded-update', action='store_true',
+                    help="N > 1: the first linear layer's gradient is reduce-scattered by rows, each rank updates its rows and the "
+                         'updated bf16 rows are all-gathered (same arithmetic; ignores --dp-transport/--dp-algo).  Default: every rank '
+                         "all-reduces that gradient and updates the whole layer - the path with the most multi-rank coverage")
+    ap.add_argument('--dp-replicated-update', action='store_true', help='the default; accepted for older command lines')
     ap.add_argument('--no-fwd-bwd-only', action='store_true', help='skip the extra steps without the optimizer that give executor_fwd_bwd')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of vqa_amd.optim.FusedAdam")
     ap.add_argument('--cpu-programs', action='store_true', help='hand the programs over as host tensors (the data loader\'s), '
@@ -60,6 +66,9 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=64, help='batch of the CPU baseline (BASELINE config 1: 64)')
     ap.add_argument('--cpu-reps', type=int, default=3, help='timed repetitions of the CPU baseline')
     a = ap.parse_args()
+    if a.dp_sharded_update and (a.dp_replicated_update or a.dp_transport != 'fp32' or a.dp_algo != 'all_reduce'):
+        ap.error('--dp-sharded-update excludes --dp-replicated-update, --dp-transport and --dp-algo '
+                 "(a sharded layer's gradient is reduce-scattered in fp32)")
     preset = {3: dict(batch=1024, module_dim=128, max_len=30, max_nodes=27),
               5: dict(batch=512, module_dim=256, max_len=64, max_nodes=60)}[a.config]
     for k, v in preset.items():
@@ -106,8 +115,37 @@ def cpu_baseline(vocab, batch, reps):
                       '(median %.2f s, `value`)' % (batch, reps, tf, tb)}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: one rank per GPU is started
+    through torch.distributed.run as a child process of this one, which has not touched a GPU (no
+    exec: the child is a fresh process), and whose only job is to pass on the result line and the
+    exit code.  Rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: starting %d ranks: %s' % (a.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE)
+    lines = [ln for ln in r.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+    for ln in r.stdout.decode(errors='replace').splitlines():
+        if not ln.startswith('{'):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print('bench.py: the ranks ended without a result line', file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
     # stdout carries exactly one line, the result: whatever libraries print there (RCCL's version
     # banner at communicator set-up, for one) is sent to stderr instead
     result_fd = os.dup(1)
@@ -117,9 +155,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run '
-                             '--nproc-per-node %d' % (a.gpus, a.gpus))
+        print('bench.py: --gpus %d but the launcher started %d ranks: running %d' % (a.gpus, world, world), file=sys.stderr)
         a.gpus = world
     # diagnostics: all ranks on GPU 0 with gloo between them (a one-GPU box cannot host two RCCL
     # ranks) - exercises this script's multi-rank path; the figures it prints mean nothing
@@ -162,7 +198,7 @@ def main():
     if world > 1 or force_dp:
         from vqa_amd.dp import DataParallelExecutor
         step_net = DataParallelExecutor(net, big_transport=a.dp_transport, big_algo=a.dp_algo,
-                                        shard_big_update=not a.dp_replicated_update and not a.torch_adam and not a.no_optimizer)
+                                        shard_big_update=a.dp_sharded_update and not a.torch_adam and not a.no_optimizer)
     opt = None
     if not a.no_optimizer:
         # Train_model.py:165-167: Adam, lr 1e-4, weight_decay 5e-5
@@ -274,10 +310,12 @@ def main():
         torch.cuda.synchronize()
         fb_ms = (time.perf_counter() - t1) / nfb * 1e3
         fb_flops = sum(flops_exec_step[(a.warmup + a.steps + 1 + i) % len(batches)] for i in range(nfb)) / nfb
+    rank_ms = [dt / a.steps * 1e3]
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        every = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([dt], device=dev, dtype=torch.float64))
+        rank_ms = [t.item() / a.steps * 1e3 for t in every]
+        dt = max(t.item() for t in every)
 
     if rank == 0:
         idx = [(a.warmup + i) % len(batches) for i in range(a.steps)]
@@ -327,6 +365,7 @@ def main():
             hbm = {'bytes_per_step': sj['hbm_bytes_per_step'], 'achieved_gbps': sj['hbm_bytes_per_step'] / (dt / a.steps) / 1e9,
                    'peak_gbps': 8000.0, 'frac': sj['hbm_bytes_per_step'] / (dt / a.steps) / 8e12,
                    'source': source_of(spath, sj), 'method': sj['method']}
+        sharded = world > 1 and a.dp_sharded_update and not a.torch_adam and not a.no_optimizer
         out = {
             'metric': 'programs/sec (module-net fwd+bwd, whole node)',
             'value': a.batch * world * a.steps / dt,
@@ -339,7 +378,8 @@ def main():
                                    'accumulation, batch %d/GPU, %s ModuleNet, random '
                                    'well-formed CLEVR-style programs (<=%d nodes, T=%d, mean %.1f nodes), '
                                    'features %s, programs %s'
-                                   % ((' + RCCL gradient all-reduce (large gradient: %s, %s)' % (a.dp_transport, a.dp_algo)) if world > 1 else '',
+                                   % (('' if world == 1 else " + RCCL gradient exchange (first linear layer's gradient reduce-scattered by rows)"
+                                       if sharded else ' + RCCL gradient all-reduce (large gradient: %s, %s)' % (a.dp_transport, a.dp_algo)),
                                       '' if a.no_optimizer else (' + torch fused Adam' if a.torch_adam else ' + Adam (vqa_amd.optim.FusedAdam)'), a.batch,
                                       'default 117.5 M-parameter' if a.module_dim == 128 else 'module width %d' % a.module_dim,
                                       a.max_nodes, a.max_len,
@@ -349,7 +389,7 @@ def main():
                                       'in host memory' if a.cpu_programs else 'resident in HBM'),
                        'global_batch': a.batch * world,
                        'parallelism': 'dp%d' % world + ('' if world == 1 else (
-                           ', every rank updates all parameters' if (a.dp_replicated_update or a.torch_adam or a.no_optimizer) else
+                           ', every rank updates all parameters' if not sharded else
                            ", first linear layer's gradient reduce-scattered by rows, its Adam update and bf16 copy "
                            'sharded over the ranks (same arithmetic as the replicated update)'))},
             # executed: what the device runs (the scene nodes of a sample are one computation);
@@ -378,6 +418,12 @@ def main():
                 'mfma_peak_frac': fb_flops / (fb_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                 'note': 'forward + cross-entropy + backward without the optimizer step, %d steps after the timed region; '
                         'not the headline: `value` is the whole training step' % min(a.steps, 10)}
+        if world > 1 or force_dp:
+            # what ran between the ranks, so that a first multi-GPU line can be read without the code
+            out['ranks'] = {'n': world, 'ms_per_step_min': min(rank_ms), 'ms_per_step_max': max(rank_ms),
+                            'ms_per_step': rank_ms, 'backend': dist.get_backend(),
+                            'large_gradient': 'reduce-scatter by rows + sharded Adam + all-gather of bf16 rows' if sharded else
+                                              '%s %s, every rank updates the whole layer' % (a.dp_transport, a.dp_algo)}
         if rehearse:
             out['rehearsal'] = 'all ranks on one GPU, gloo through the host: not a measurement'
         if not a.no_cpu_baseline and world == 1:

@@ -37,23 +37,46 @@ def test_one_json_line_with_the_agreed_keys():
     assert 0 < fb['ms_per_step'] and fb['mfma_peak_frac'] > 0 and 'not the headline' in fb['note']
 
 
+def _rehearse(cmd):
+    env = dict(os.environ, VQA_BENCH_REHEARSE_SHARED_GPU='1')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['global_batch'] == 128
+    assert abs(d['value'] - 128 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+    assert 'rehearsal' in d
+    assert 'cpu_baseline' not in d and 'executor_fwd_bwd' not in d          # rank 0 at N = 1 only
+    rk = d['ranks']
+    assert rk['n'] == 2 and len(rk['ms_per_step']) == 2 and rk['backend'] == 'gloo'
+    assert rk['ms_per_step_min'] <= rk['ms_per_step_max'] == d['ms_per_step']
+    return d
+
+
 def test_two_rank_launch_path_rehearsed_on_one_gpu():
     """The script's multi-rank path as the driver launches it (torch.distributed.run, one process per
     rank, RANK/LOCAL_RANK/WORLD_SIZE from the environment): both ranks on this box's one GPU with the
     collectives staged through the host (VQA_BENCH_REHEARSE_SHARED_GPU; the figures mean nothing).
-    One JSON line from rank 0, whole-job values, the sharded update of the first linear layer named."""
+    One JSON line from rank 0, whole-job values; by default every rank updates all parameters, and the
+    sharded update of the first linear layer is named when it is asked for."""
     import socket
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, VQA_BENCH_REHEARSE_SHARED_GPU='1')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
-                        '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '64', '--batches', '1'],
-                       capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['global_batch'] == 128
-    assert abs(d['value'] - 128 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
-    assert 'sharded over the ranks' in d['config']['parallelism'] and 'rehearsal' in d
-    assert 'cpu_baseline' not in d and 'executor_fwd_bwd' not in d          # rank 0 at N = 1 only
+    launch = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+              '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+              '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '64', '--batches', '1']
+    d = _rehearse(launch)
+    assert 'every rank updates all parameters' in d['config']['parallelism']
+    assert 'fp32 all_reduce' in d['ranks']['large_gradient'] and 'all-reduce (large gradient: fp32, all_reduce)' in d['config']['workload']
+    d = _rehearse(launch + ['--dp-sharded-update'])
+    assert 'sharded over the ranks' in d['config']['parallelism'] and 'reduce-scatter' in d['ranks']['large_gradient']
+    assert 'large gradient:' not in d['config']['workload']
+
+
+def test_plain_start_with_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form a one-GPU run is started in): the
+    script starts torch.distributed.run on itself as a child process, relays the one result line and
+    the exit code."""
+    _rehearse([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+               '--batch', '64', '--batches', '1'])

@@ -200,3 +200,119 @@ def _worker_big_modes(rank, world, port):
 
 def test_large_gradient_transports_and_algorithms_two_ranks_gloo():
     mp.spawn(_worker_big_modes, args=(2, _free_port()), nprocs=2, join=True)
+
+
+class _FakeShardNet(_FakeNet):
+    """What DataParallelExecutor(shard_big_update=True) looks at on the executor: the bf16 path, the
+    index of the first linear layer, and an optimizer that said it can apply a slice of rows."""
+
+    def __init__(self, with_optimizer=True, precision='bf16'):
+        super().__init__()
+        self._fc_idx = [3]
+        self.precision = precision
+        holder = nn.Module()
+        holder.weight = self.big
+        self.classifier = {3: holder}
+        self._fc1_grad_shard = None
+        self._fc1_gather = None
+        self._fc1_master_stale = False
+        import weakref
+
+        class _Opt:
+            pass
+        self._opt = _Opt()          # kept alive here: the executor holds a weak reference only
+        self._sliced_update_optimizer = weakref.ref(self._opt) if with_optimizer else None
+
+
+def _worker_sharded(rank, world, port):
+    """The first linear layer's update split over 8 ranks (F / 8 rows each, the split of a whole node):
+    every rank ends up with the average of ITS rows only and no .grad on the parameter; the updated
+    bf16 rows of all ranks are exchanged; a slice that no optimizer applied, a second backward pass
+    before the sync, an optimizer that cannot apply slices and the fp32 path are all handled loudly
+    or by falling back to the replicated all-reduce."""
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        F = 64
+        rows = F // world
+        base = torch.arange(1, F + 1, dtype=torch.float32)[:, None].expand(F, 64)
+        net = _FakeShardNet()
+        dp = DataParallelExecutor(net, direct_bytes=64 * 64 * 4, shard_big_update=True)
+        for step in range(2):
+            net.last_token_counts = [1, 1, 0]
+            dp(torch.zeros(1), None)
+            net.fake_backward({'classifier.3.weight': (base * (rank + 1 + step)).contiguous(),
+                               'scene.conv1.weight': torch.full((4, 3), float(rank)),
+                               '<NULL>.conv1.weight': torch.ones(4, 3)})
+            dp.finish_grad_sync()
+            assert net.big.grad is None
+            shard, r, w, owner = net._fc1_grad_shard
+            assert (r, w, owner) == (rank, world, dp) and shard.numel() == rows * 64
+            mean_factor = sum(k + 1 + step for k in range(world)) / world
+            want = base[rank * rows:(rank + 1) * rows] * mean_factor
+            assert torch.allclose(shard.view(rows, 64), want, rtol=1e-6)
+            assert torch.allclose(net.mods['scene'].grad, torch.full((4, 3), (world - 1) / 2.0))
+            # the optimizer's part: take the slice, update these rows of the bf16 copy, exchange
+            net._fc1_grad_shard = None
+            packed = torch.zeros(F, 64, dtype=torch.bfloat16)
+            packed[rank * rows:(rank + 1) * rows] = float(10 * step + rank + 1)
+            dp.gather_big_packed(packed)
+            net._fc1_gather.wait()
+            want_rows = torch.arange(world, dtype=torch.float32).repeat_interleave(rows) + 10 * step + 1
+            assert torch.equal(packed.float(), want_rows[:, None].expand(F, 64))
+            assert net._fc1_master_stale
+        # the fp32 copy of the layer is current on the owning rank only until it is gathered
+        net.big.data.zero_()
+        net.big.data[rank * rows:(rank + 1) * rows] = float(rank + 1)
+        dp.gather_sharded_state()
+        assert torch.equal(net.big.data[:, 0], torch.arange(world, dtype=torch.float32).repeat_interleave(rows) + 1)
+        assert not net._fc1_master_stale
+
+        # a slice nobody applied: the next backward pass refuses to replace it
+        net.last_token_counts = [1, 1, 0]
+        dp(torch.zeros(1), None)
+        net.fake_backward({'classifier.3.weight': base.contiguous(), 'scene.conv1.weight': torch.ones(4, 3)})
+        dp.finish_grad_sync()
+        dp(torch.zeros(1), None)
+        try:
+            net.fake_backward({'classifier.3.weight': base.contiguous(), 'scene.conv1.weight': torch.ones(4, 3)})
+            raise AssertionError('an unapplied slice was overwritten')
+        except RuntimeError as e:
+            assert 'never applied' in str(e)
+
+        # no optimizer that applies slices, or the fp32 path: the replicated all-reduce, .grad on the parameter
+        for kw in (dict(with_optimizer=False), dict(precision='fp32')):
+            net2 = _FakeShardNet(**kw)
+            dp2 = DataParallelExecutor(net2, direct_bytes=64 * 64 * 4, shard_big_update=True)
+            net2.last_token_counts = [1, 1, 0]
+            dp2(torch.zeros(1), None)
+            net2.fake_backward({'classifier.3.weight': (base * (rank + 1)).contiguous(),
+                                'scene.conv1.weight': torch.ones(4, 3)})
+            dp2.finish_grad_sync()
+            assert net2._fc1_grad_shard is None
+            assert torch.allclose(net2.big.grad, base * ((world + 1) / 2.0), rtol=1e-6)
+
+        # two backward passes before the sync: refused before anything of the second is issued
+        net3 = _FakeNet()
+        dp3 = DataParallelExecutor(net3, direct_bytes=64 * 64 * 4)
+        net3.last_token_counts = [1, 1, 0]
+        dp3(torch.zeros(1), None)
+        g = {'classifier.3.weight': torch.ones(64, 64), 'scene.conv1.weight': torch.ones(4, 3)}
+        net3.fake_backward(g)
+        try:
+            net3.fake_backward(g)
+            raise AssertionError('a second backward pass went through')
+        except RuntimeError as e:
+            assert 'second backward pass' in str(e)
+        dp3.finish_grad_sync()            # the first pass is intact
+        assert torch.allclose(net3.big.grad, torch.ones(64, 64))
+        net3.last_token_counts = [1, 1, 0]
+        dp3(torch.zeros(1), None)
+        net3.fake_backward(g)             # and the next step runs
+        dp3.finish_grad_sync()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_update_of_the_large_layer_eight_ranks_gloo():
+    mp.spawn(_worker_sharded, args=(8, _free_port()), nprocs=8, join=True)

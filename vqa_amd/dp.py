@@ -93,12 +93,15 @@ class DataParallelExecutor:
         self._zeros = None
         self._groups = []            # (array, {name: row}) handed over by the executor this step
         self._grouped_names = set()  # names that arrive as rows of such arrays (fixed after the first step)
+        self._row_tables = {}        # id(name -> row dict) -> (that dict, [(parameter, token index, row)])
+        self._ungrouped = None       # (len(_grouped_names) it was made for, [(name, parameter)] outside the arrays)
         self._small_groups = []
         self._works = []
         self._direct = {}
         self._small = {}
         self._presence = None
         self._pending = False
+        self._backward_done = False  # a backward pass has run since the last finish_grad_sync()
         net.grad_ready_hook = self._on_grad
         net.grad_group_hook = self._on_group
         net.plan_ready_hook = self._on_plan
@@ -182,19 +185,41 @@ class DataParallelExecutor:
         w.wait()       # RCCL: the current stream waits, the host does not; the all-gather reads the slice
         self._works.append(dist.all_gather_into_tensor(src, shard, group=self.pg, async_op=True))
 
+    def _has_slicing_optimizer(self):
+        ref = getattr(self.net, '_sliced_update_optimizer', None)
+        return ref is not None and ref() is not None
+
     def _shardable(self, name, grad):
-        """Only the executor's first linear layer, whose update vqa_amd.optim.FusedAdam can run on a
-        slice of rows."""
+        """Only the executor's first linear layer on the bf16 path, and only when an optimizer that
+        can run its update on a slice of rows has said so (vqa_amd.optim.FusedAdam(executor=net)
+        registers itself on the executor): with any other optimizer the slice would never be
+        applied, so the gradient takes the replicated all-reduce instead."""
         net = self.net
         idx = getattr(net, '_fc_idx', None)
         return (self.shard_big_update and idx is not None and
+                getattr(net, 'precision', None) == 'bf16' and self._has_slicing_optimizer() and
                 name == 'classifier.%d.weight' % idx[0] and grad.dim() == 2 and grad.shape[0] % self.world == 0 and
                 grad.dtype == torch.float32)
 
+    def _one_backward_per_sync(self):
+        """torch.nn.DataParallel lets a caller run several backward passes before the optimizer step and
+        sums them; here the gradients of a pass live in the executor's own arrays and are reduced in
+        place while the pass runs, so a second pass would overwrite the first one's.  Refused loudly,
+        before anything of the second pass is issued (every rank takes the same branch)."""
+        if self._backward_done:
+            raise RuntimeError('DataParallelExecutor: a second backward pass before finish_grad_sync(); gradient '
+                               'accumulation over several passes is not supported - call finish_grad_sync() and the '
+                               'optimizer step after every backward pass, or sum the losses and run one pass')
+
     def _on_grad(self, name, grad):
+        self._one_backward_per_sync()
         self._pending = True
         if grad.numel() * grad.element_size() >= self.direct_bytes and grad.is_contiguous():
             if self._shardable(name, grad):
+                if getattr(self.net, '_fc1_grad_shard', None) is not None:
+                    raise RuntimeError("DataParallelExecutor(shard_big_update=True): the previous step's rows of the first "
+                                       "linear layer's gradient were never applied - FusedAdam(executor=net).step() has "
+                                       'to run between finish_grad_sync() and the next backward pass')
                 n = grad.numel() // self.world
                 shard = self._shard_bufs.get(name)
                 if shard is None or shard.numel() != n or shard.device != grad.device:
@@ -212,6 +237,7 @@ class DataParallelExecutor:
     def _on_group(self, array, rows):
         """`array` [V, ...] holds the gradients of one parameter kind of every token (zeros where a
         token was not used); rows maps parameter name -> row."""
+        self._one_backward_per_sync()
         self._pending = True
         if self._flat is not None and not self._grouped_names.issuperset(rows):
             self._flat = None                # first sight of these names after the bucket was laid out
@@ -238,6 +264,7 @@ class DataParallelExecutor:
         self._flat = torch.zeros(off, dtype=torch.float32, device=device)
 
     def _on_backward_done(self):
+        self._backward_done = True
         dev = next(iter(self._small.values())).device if self._small else self._params[0][1].device
         self._ensure_flat(dev)
         # the bucket in one launch: the pieces in layout order, zeros where this step has no gradient
@@ -290,22 +317,26 @@ class DataParallelExecutor:
             off, cnt = self._layout[('group', k)]                  # their parameters' .grad become views of it
             groups.append((self._flat[off:off + cnt].view(array.shape), rows))
         # A parameter whose token this rank used already has its row of the array as .grad (autograd
-        # installed it; the reduction was in place): only the others are touched.
+        # installed it; the reduction was in place): only the others are touched.  The executor hands
+        # over the same name -> row dict every step, so the (parameter, token, row) table of a group is
+        # made once; per parameter and step this loop is then an attribute read and a pointer compare.
         by_name, token_of = self._by_name, self._token_of
         for array, rows in groups:
+            ent = self._row_tables.get(id(rows))
+            if ent is None or ent[0] is not rows:
+                ent = self._row_tables[id(rows)] = (rows, [(by_name[n], token_of[n], row) for n, row in rows.items()])
             base, row_bytes = array.data_ptr(), array[0].numel() * array.element_size()
-            for n, row in rows.items():
-                p = by_name[n]
-                if present is not None and not present[token_of[n]]:
+            for p, ti, row in ent[1]:
+                if present is not None and not present[ti]:
                     if p.grad is not None:
                         p.grad = None         # unused on every rank
                     continue
                 g = p.grad
                 if g is None or g.data_ptr() != base + row * row_bytes:
                     p.grad = array[row].view(p.shape)
-        for n, p in self._params:
-            if n in self._grouped_names:
-                continue
+        if self._ungrouped is None or self._ungrouped[0] != len(self._grouped_names):
+            self._ungrouped = (len(self._grouped_names), [(n, p) for n, p in self._params if n not in self._grouped_names])
+        for n, p in self._ungrouped[1]:
             if n in self._sharded:
                 # this rank's rows of the averaged gradient, for FusedAdam's update of the same rows
                 shard = self._sharded[n]
@@ -332,6 +363,7 @@ class DataParallelExecutor:
         self._sharded, self._keep_big = {}, None
         self._groups, self._small_groups = [], []
         self._presence_launched = False
+        self._backward_done = False
 
     # ---------------------------------------------------------------- sharded update of the first linear layer
     def gather_big_packed(self, packed):

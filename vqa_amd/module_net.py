@@ -234,6 +234,8 @@ class ModuleNet(nn.Module):
         # linear layer's averaged gradient; the all-gather of the updated bf16 rows still in flight;
         # whether the fp32 master copy is current on its owning ranks only
         self._fc1_grad_shard = None
+        self._group_rows = None                  # parameter kind -> {parameter name: row of the per-token gradient array}
+        self._sliced_update_optimizer = None     # weak reference to a FusedAdam(executor=self), set by it
         self._fc1_gather = None
         self._fc1_master_stale = False
         self.used_fns = None
@@ -1295,10 +1297,14 @@ class ModuleNet(nn.Module):
         self._mark('tree_bwd')
         if self.grad_group_hook is not None:
             # the per-token gradients are rows of these arrays (zeros for tokens this batch did not use)
-            for arr, key, binary_only in ((gw1, '.conv1.weight', False), (gw2, '.conv2.weight', False),
-                                          (gwp, '.proj.weight', True), (acc['gb_conv1'], '.conv1.bias', False),
-                                          (acc['gb_conv2'], '.conv2.bias', False), (acc['gb_proj'], '.proj.bias', True)):
-                rows = {tok + key: i for i, tok in enumerate(self._tokens) if self._binary[i] or not binary_only}
+            # (the same name -> row dict objects every step: a receiver may key its own tables on them)
+            if self._group_rows is None:
+                self._group_rows = {key: {tok + key: i for i, tok in enumerate(self._tokens) if self._binary[i] or not binary_only}
+                                    for key, binary_only in (('.conv1.weight', False), ('.conv2.weight', False), ('.proj.weight', True),
+                                                             ('.conv1.bias', False), ('.conv2.bias', False), ('.proj.bias', True))}
+            for arr, key in ((gw1, '.conv1.weight'), (gw2, '.conv2.weight'), (gwp, '.proj.weight'),
+                             (acc['gb_conv1'], '.conv1.bias'), (acc['gb_conv2'], '.conv2.bias'), (acc['gb_proj'], '.proj.bias')):
+                rows = self._group_rows[key]
                 self.grad_group_hook(arr, rows)
                 emitted.update(rows)
         counts = plan.token_counts()

@@ -10,6 +10,7 @@ reads, so the executor does not re-pack that tensor on its next forward.
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -30,6 +31,10 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError('invalid Adam hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._executor = executor
+        if executor is not None:
+            # what a data-parallel wrapper asks before it hands this optimizer a slice of the first
+            # linear layer's gradient instead of the whole of it (step() applies such a slice)
+            executor._sliced_update_optimizer = weakref.ref(self)
         self._host = {}          # device -> two [pinned byte buffer, device byte buffer, event, numpy view] + toggle
         self._recs = {}          # group index -> per-parameter records (see _records)
         self._chunks_key, self._chunks = None, None
