@@ -510,7 +510,9 @@ typedef struct {
     const float *b_conv1, *b_conv2, *b_proj;    /* fp32 [V][C] */
     float *g_conv1, *g_conv2, *g_proj;          /* out: fp32 weight gradients in torch's layout,
                                                    [V][C][C][3][3] and [V][C][2C][1][1] (all written) */
-    float *gb_conv1, *gb_conv2, *gb_proj;       /* fp32 [V][C], accumulated into: zero them first */
+    float *gb_conv1, *gb_conv2, *gb_proj;       /* out: fp32 bias gradients [V][C]; required (gb_proj when the plan
+                                                   has binary nodes).  bf16 path: written whole, rows of unused
+                                                   tokens as zeros.  VQA_TREE_F32: accumulated into - zero them first */
     float* wgrad_partial;                       /* workspace of vqa_tree_backward:
                                                    vqa_plan_info.wgrad_partial_blocks * 8192 floats */
     int32_t C, V;

@@ -85,9 +85,14 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
 
 extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void* stream) {
     if (!pl || !c || !c->arena || !c->blob || !c->wd_conv1 || !c->wd_conv2 || !c->g_conv1 || !c->g_conv2 ||
-        !c->gb_conv1 || !c->gb_conv2 || (!c->wgrad_partial && !(c->flags & VQA_TREE_F32)) || c->C != pl->C ||
-        (pl->num_binary > 0 && (!c->wd_proj || !c->g_proj || !c->gb_proj))) {
+        (!c->wgrad_partial && !(c->flags & VQA_TREE_F32)) || c->C != pl->C ||
+        (pl->num_binary > 0 && (!c->wd_proj || !c->g_proj))) {
         vqa_set_error("vqa_tree_backward: bad argument");
+        return VQA_EINVAL;
+    }
+    if (!c->gb_conv1 || !c->gb_conv2 || (pl->num_binary > 0 && !c->gb_proj)) {
+        vqa_set_error("vqa_tree_backward: the bias-gradient arrays gb_conv1, gb_conv2 (and gb_proj for plans with binary "
+                      "nodes) are required");
         return VQA_EINVAL;
     }
     if (pl->shared) {

@@ -313,9 +313,12 @@ class DataParallelExecutor:
         if not self._avg:
             for array, _ in groups:
                 array.mul_(scale)            # reduced in place as sums
-        for k, (array, rows) in enumerate(self._small_groups):     # these travelled in the flat bucket:
-            off, cnt = self._layout[('group', k)]                  # their parameters' .grad become views of it
-            groups.append((self._flat[off:off + cnt].view(array.shape), rows))
+        for k, (array, rows) in enumerate(self._small_groups):
+            # these travelled in the flat bucket: the averages go back into the array, whose rows the
+            # parameters already have as .grad (one small copy instead of a new view per parameter)
+            off, cnt = self._layout[('group', k)]
+            array.copy_(self._flat[off:off + cnt].view(array.shape))
+            groups.append((array, rows))
         # A parameter whose token this rank used already has its row of the array as .grad (autograd
         # installed it; the reduction was in place): only the others are touched.  The executor hands
         # over the same name -> row dict every step, so the (parameter, token, row) table of a group is
