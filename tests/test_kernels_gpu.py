@@ -439,6 +439,37 @@ def test_gemm_large_tiles_all_layouts():
     close(cb.to(torch.float32).cpu(), ref * (mk > 0))
 
 
+@pytest.mark.parametrize('K', [64, 256, 320, 1024])
+def test_gemm_large_tiles_k_major_b_any_k_depth(K):
+    """The shapes of the first linear layer's backward GEMMs on the 256 x 256-tile kernel (A k-contiguous,
+    B k-major, M and N multiples of 256), whose LDS fragment reads carry their own counted waits while
+    the next stage's LDS-DMA is in flight: one K step (no next stage), four, five (odd: the buffers
+    swap an odd number of times), sixteen (the layer's).  fp32 result, masked bf16 result, and operands
+    inside wider arrays."""
+    from vqa_amd import ops
+    M, N = 512, 16384
+    a, b = bf(rnd((M, K), 70)) * 0.25, bf(rnd((K, N), 71)) * 0.25
+    ref = a @ b
+    ad, bd = a.to(torch.bfloat16).to(dev()), b.to(torch.bfloat16).to(dev())
+    c = torch.full((M, N), 7.0, device=dev())
+    ops.gemm(ad, bd, c, M, N, K, lda=K, ldb=N, ldc=N, b_kmajor=True)
+    torch.cuda.synchronize()
+    close(c.cpu(), ref, 2e-3)
+    mk = bf(F.relu(rnd((M, N), 72)))
+    cb = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(ad, bd, cb, M, N, K, lda=K, ldb=N, ldc=N, b_kmajor=True, out_bf16=True, mask=mk.to(torch.bfloat16).to(dev()))
+    torch.cuda.synchronize()
+    close(cb.to(torch.float32).cpu(), ref * (mk > 0))
+    # leading dimensions larger than the rows (operands inside wider arrays)
+    aw = torch.zeros(M, K + 64, dtype=torch.bfloat16, device=dev()); aw[:, :K] = ad
+    bw = torch.zeros(K, N + 256, dtype=torch.bfloat16, device=dev()); bw[:, :N] = bd
+    cw = torch.full((M, N + 8), 7.0, device=dev())
+    ops.gemm(aw, bw, cw, M, N, K, lda=K + 64, ldb=N + 256, ldc=N + 8, b_kmajor=True)
+    torch.cuda.synchronize()
+    close(cw.cpu()[:, :N], ref, 2e-3)
+    assert (cw[:, N:] == 7.0).all()
+
+
 def test_layout_helpers():
     from vqa_amd import ops
     n, cin, cpad = 3, 100, 128

@@ -50,6 +50,32 @@ __device__ __forceinline__ bf16x8 frag_km(const char* lds, int col0, int ks, int
     return frag_from_tr(lo, hi);
 }
 
+// The same two fragment reads as inline assembly, for loops that keep LDS-DMA writes in flight while
+// they read (see gemm256_kernel): `lds` is the tile's LDS byte address.
+__device__ __forceinline__ uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)(LDS_AS const char*)p; }
+__device__ __forceinline__ bf16x8 frag_kc_asm(uint32_t lds, int row0, int ks, int lane) {
+    const int row = row0 + (lane & 15), kc = ks * 4 + (lane >> 4);
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds + row * 128 + ((kc ^ (row & 7)) << 4)));
+    return v;
+}
+__device__ __forceinline__ bf16x8 frag_km_asm(uint32_t lds, int col0, int ks, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int j = (col0 >> 3) + (pp >> 1), sub = (pp & 1) * 8;
+    const int r0 = ks * 32 + 8 * g + q, r1 = r0 + 4;
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(lds + r0 * 256 + ((j ^ sw_km(r0)) << 4) + sub));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(lds + r1 * 256 + ((j ^ sw_km(r1)) << 4) + sub));
+    return frag_from_tr(lo, hi);
+}
+// s_waitcnt lgkmcnt(N), tied to the registers it is for: nothing that uses them can be scheduled ahead of it
+template <int N>
+__device__ __forceinline__ void wait_lgkm_for1(bf16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void wait_lgkm_for5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}
+
 template <bool A_KM, bool B_KM, int STAGES>
 __global__ __launch_bounds__(256) void gemm_kernel(vqa_gemm_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,34 +270,50 @@ __global__ __launch_bounds__(512) void gemm256_kernel(vqa_gemm_params p) {
         // turns.  So the second half's fragments are read under the first half's MFMAs: row block mi
         // of A is multiplied with all four column blocks, then its registers take the second half's
         // fragment; only B's second half needs registers of its own.
+        //
+        // The fragment reads are inline assembly with their own two waits per K step.  Left to the
+        // compiler, which cannot tell a read of this stage from the LDS-DMA writes of the next one
+        // (issued a few lines up), every first read got an s_waitcnt vmcnt(0) in front: the next stage
+        // was waited for before this one was multiplied, and a K step lasted a trip to HBM plus its
+        // MFMA time.  A wait is tied to the registers it is for, so nothing that uses them can be
+        // scheduled ahead of it; the registers go from the reads straight into the MFMAs.
+        const uint32_t la_o = lds_off(la), lb_o = lds_off(lb);
+        // LDS instructions per fragment, and the waits counted in them (reads return in order; the counter
+        // holds 15 at most): B's first half goes out first, then A's eight row blocks; in front of row
+        // block mi the reads issued behind its fragment may still be pending - the later row blocks and
+        // the second-half fragments read so far.
+        constexpr int UA = A_KM ? 2 : 1, UB = B_KM ? 2 : 1;
         bf16x8 af[8], bfr[4], bfr1[4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) af[i] = A_KM ? frag_km(la, i * 16, 0, lane) : frag_kc(la, i * 16, 0, lane);
+        for (int i = 0; i < 4; i++) bfr[i] = B_KM ? frag_km_asm(lb_o, cb + i * 16, 0, lane) : frag_kc_asm(lb_o, cb + i * 16, 0, lane);
 #pragma unroll
-        for (int i = 0; i < 4; i++) bfr[i] = B_KM ? frag_km(lb, cb + i * 16, 0, lane) : frag_kc(lb, cb + i * 16, 0, lane);
+        for (int i = 0; i < 8; i++) af[i] = A_KM ? frag_km_asm(la_o, i * 16, 0, lane) : frag_kc_asm(la_o, i * 16, 0, lane);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mi = 0; mi < 8; mi++) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) acc[ni][mi] = mma16(bfr[ni], af[mi], acc[ni][mi]);
-            af[mi] = A_KM ? frag_km(la, mi * 16, 1, lane) : frag_kc(la, mi * 16, 1, lane);
-            if (mi < 4) bfr1[mi] = B_KM ? frag_km(lb, cb + mi * 16, 1, lane) : frag_kc(lb, cb + mi * 16, 1, lane);
+#define GEMM_ROWBLOCK(mi)                                                                                      \
+        {                                                                                                      \
+            constexpr int pend = 7 * UA + ((mi) < 4 ? (mi) : 4) * UB;                                          \
+            if ((mi) == 0) wait_lgkm_for5<(pend < 15 ? pend : 15)>(bfr[0], bfr[1], bfr[2], bfr[3], af[0]);     \
+            else wait_lgkm_for1<(pend < 15 ? pend : 15)>(af[mi]);                                              \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ni++) acc[ni][mi] = mma16(bfr[ni], af[mi], acc[ni][mi]); \
+            af[mi] = A_KM ? frag_km_asm(la_o, (mi) * 16, 1, lane) : frag_kc_asm(la_o, (mi) * 16, 1, lane);     \
+            if ((mi) < 4) bfr1[(mi) & 3] = B_KM ? frag_km_asm(lb_o, cb + ((mi) & 3) * 16, 1, lane) : frag_kc_asm(lb_o, cb + ((mi) & 3) * 16, 1, lane); \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
         }
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, (A_KM ? 2 : 1) + (B_KM ? 2 : 1), 0);
+        GEMM_ROWBLOCK(0) GEMM_ROWBLOCK(1) GEMM_ROWBLOCK(2) GEMM_ROWBLOCK(3)
+        GEMM_ROWBLOCK(4) GEMM_ROWBLOCK(5) GEMM_ROWBLOCK(6) GEMM_ROWBLOCK(7)
+#undef GEMM_ROWBLOCK
+        // second half: its fragments went out in the order A'0 B'0 A'1 B'1 A'2 B'2 A'3 B'3 A'4 .. A'7
+#define GEMM_ROWBLOCK2(mi)                                                                                     \
+        {                                                                                                      \
+            constexpr int pend = ((mi) < 4 ? 4 : 7 - (mi)) * UA;                                               \
+            if ((mi) == 0) wait_lgkm_for5<pend>(bfr1[0], bfr1[1], bfr1[2], bfr1[3], af[0]);                    \
+            else wait_lgkm_for1<pend>(af[mi]);                                                                 \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ni++) acc[ni][mi] = mma16(bfr1[ni], af[mi], acc[ni][mi]); \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
         }
-#pragma unroll
-        for (int mi = 4; mi < 8; mi++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, A_KM ? 2 : 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mi = 0; mi < 8; mi++)
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) acc[ni][mi] = mma16(bfr1[ni], af[mi], acc[ni][mi]);
+        GEMM_ROWBLOCK2(0) GEMM_ROWBLOCK2(1) GEMM_ROWBLOCK2(2) GEMM_ROWBLOCK2(3)
+        GEMM_ROWBLOCK2(4) GEMM_ROWBLOCK2(5) GEMM_ROWBLOCK2(6) GEMM_ROWBLOCK2(7)
+#undef GEMM_ROWBLOCK2
     }
 
     // epilogue: two passes of 128 rows through an fp32 [128][264] LDS tile, whole-row stores
