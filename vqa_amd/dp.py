@@ -94,6 +94,7 @@ class DataParallelExecutor:
         self._groups = []            # (array, {name: row}) handed over by the executor this step
         self._grouped_names = set()  # names that arrive as rows of such arrays (fixed after the first step)
         self._row_tables = {}        # id(name -> row dict) -> (that dict, [(parameter, token index, row)])
+        self._rows_checked = {}      # id(name -> row dict) -> (array address, tokens used here, tokens used anywhere) last checked
         self._ungrouped = None       # (len(_grouped_names) it was made for, [(name, parameter)] outside the arrays)
         self._small_groups = []
         self._works = []
@@ -324,11 +325,23 @@ class DataParallelExecutor:
         # over the same name -> row dict every step, so the (parameter, token, row) table of a group is
         # made once; per parameter and step this loop is then an attribute read and a pointer compare.
         by_name, token_of = self._by_name, self._token_of
+        counts = getattr(self.net, 'last_token_counts', None)
+        local = tuple(1 if c else 0 for c in counts) if counts is not None else None
+        present = tuple(present) if present is not None else None
         for array, rows in groups:
             ent = self._row_tables.get(id(rows))
             if ent is None or ent[0] is not rows:
                 ent = self._row_tables[id(rows)] = (rows, [(by_name[n], token_of[n], row) for n, row in rows.items()])
             base, row_bytes = array.data_ptr(), array[0].numel() * array.element_size()
+            # Same array address, same tokens present on this rank and anywhere as in a step whose
+            # .grad tensors were checked one by one: autograd installs the rows the same way (whether it
+            # keeps the row view it is handed depends on the code path, not on the data), nothing to do.
+            # (only when every token used anywhere is used here: a parameter whose token only another rank
+            # used has no .grad from autograd and gets its row below, every step)
+            key = (base, local, present)
+            if local is not None and local == present and self._rows_checked.get(id(rows)) == key:
+                continue
+            self._rows_checked[id(rows)] = key
             for p, ti, row in ent[1]:
                 if present is not None and not present[ti]:
                     if p.grad is not None:
