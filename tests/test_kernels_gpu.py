@@ -179,6 +179,42 @@ def test_resblock_fused_matches_two_launches_and_torch(backward):
     close(from_slots(arena[4 * S:5 * S], C), torch.stack(out_ref), tol=2e-2)
 
 
+@pytest.mark.parametrize('backward', [False, True])
+def test_resblock_two_image_form_equals_one_image_form(backward):
+    """A launch of at most one workgroup per CU runs the two-image form of the fused kernel (second halo
+    image, residual read from LDS, conflict-free epilogue writes), a larger launch the one-image form: the
+    same nodes must come out bit for bit the same either way, a node's level size being an accident of the
+    batch.  300 tiles = 6 distinct nodes repeated, against the same 6 nodes alone."""
+    from vqa_amd import ops
+    C, G, S, R = 128, 2, 6, 50
+    x = bf(rnd((S, C, 14, 14), 71))
+    w1 = bf(rnd((G, C, C, 3, 3), 72, 0.04))
+    w2 = bf(rnd((G, C, C, 3, 3), 73, 0.04))
+    b1, b2 = rnd((G, C), 74, 0.1), rnd((G, C), 75, 0.1)
+    hmask, omask = bf(F.relu(rnd((S, C, 14, 14), 76))), bf(F.relu(rnd((S, C, 14, 14), 77)))
+    zeros = lambda k: torch.zeros(k, HW, C, dtype=torch.bfloat16, device=dev())
+    # slots: x | hmask | omask | mid, out of the small launch | mid, out of every repetition of the large one
+    arena = torch.cat([to_slots(x), to_slots(hmask), to_slots(omask), zeros(2 * S), zeros(2 * S * R)])
+    flip = dict(flip=True) if backward else {}
+    order = (9, C * 9) if backward else (C * 9, 9)
+    p1 = ops.pack_conv_weight(w1.to(dev()), G, C, C, 9, C * C * 9, *order, **flip)
+    p2 = ops.pack_conv_weight(w2.to(dev()), G, C, C, 9, C * C * 9, *order, **flip)
+    kw = dict(relu=False) if backward else dict(bias_first=b1.to(dev()), bias_second=b2.to(dev()), relu=True)
+    m1 = (lambda i: S + i) if backward else (lambda i: -1)
+    m0 = (lambda i: 2 * S + i if i % 2 else -1) if backward else (lambda i: -1)
+    row = lambda i, mid, out: [i, -1, out, mid, i, m0(i), m1(i), i % G, -1, -1, -1, -1]
+    small = tiles_tensor([row(i, 3 * S + i, 4 * S + i) for i in range(S)])
+    ops.resblock_tiles(arena, p1, p2, small, S, **kw)
+    base = 5 * S
+    large = tiles_tensor([row(i, base + (2 * r) * S + i, base + (2 * r + 1) * S + i) for r in range(R) for i in range(S)])
+    ops.resblock_tiles(arena, p1, p2, large, S * R, **kw)
+    torch.cuda.synchronize()
+    assert arena[4 * S:5 * S].float().abs().max() > 0
+    for r in range(R):
+        assert torch.equal(arena[base + 2 * r * S:base + (2 * r + 1) * S], arena[3 * S:4 * S]), r
+        assert torch.equal(arena[base + (2 * r + 1) * S:base + (2 * r + 2) * S], arena[4 * S:5 * S]), r
+
+
 def test_resblock_fused_with_projection_pre_and_post():
     """Binary nodes: the fused kernel also runs the 1x1 projection of the two children in front of the
     node's body (forward) and, backward, each child's half of the transposed projection in front of

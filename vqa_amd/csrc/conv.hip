@@ -291,6 +291,20 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 // one source load and one cold start per node.
 // ---------------------------------------------------------------------------------------------
 
+// v_permlane16_swap: the odd 16-lane rows of `a` change places with the even rows of `b`
+// (a' = a.row0 b.row0 a.row2 b.row2, b' = a.row1 b.row1 a.row3 b.row3); applied twice it is the identity.
+__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
+// this lane's bias values: 4 channels of each of the wave's two 16-channel blocks (zeros without a bias)
+__device__ __forceinline__ void lane_bias(f32x4 (&b)[2], const float* bias, int wave, int lq) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    b[0] = b[1] = z;
+    if (bias) { b[0] = *(const f32x4*)(bias + wave * 32 + lq * 4); b[1] = *(const f32x4*)(bias + wave * 32 + lq * 4 + 16); }
+}
+
 // accumulators (+ bias, ReLU) -> bf16 -> interior of the halo image; then a row-wise pass applies
 // an optional mask, rewrites the image and stores the map to `dst` in 16-byte pieces.
 template <bool MASK>
@@ -308,22 +322,24 @@ __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT
 #pragma unroll
         for (int y = 0; y < 14; y++) mv[y] = *(const uint4*)(mask + goff + y * 14 * 256);
     }
+    // the bias is asked for in front of the barrier (behind it the wait for it is all exposed)
+    f32x4 b[2];
+    lane_bias(b, bias, wave, lq);
     lds_barrier();          // every wave has finished reading the image
-    if (l15 < 14) {
+    {
+        // 16-byte conflict-free LDS writes after a swap between the lane rows: see solo_epilogue_t
+        const uint32_t floor_pk = relu ? 0u : 0x80008000u;
+        char* cell = halo + (16 + l15 + 1) * HALO_STRIDE + (wave * 32 + 16 * (lq & 1) + 8 * (lq >> 1)) * 2;
 #pragma unroll
-        for (int n = 0; n < 2; n++) {
-            const int ch = wave * 32 + n * 16 + lq * 4;
-            const f32x2 b0 = bias ? *(const f32x2*)(bias + ch) : (f32x2){0.f, 0.f};
-            const f32x2 b1 = bias ? *(const f32x2*)(bias + ch + 2) : (f32x2){0.f, 0.f};
-            char* cell = halo + (16 + l15 + 1) * HALO_STRIDE + ch * 2;
-#pragma unroll
-            for (int m = 0; m < MT; m++) {
-                uint2 pk;
-                pk.x = cvt_pk_bf16((f32x2){acc[m][n][0], acc[m][n][1]} + b0);
-                pk.y = cvt_pk_bf16((f32x2){acc[m][n][2], acc[m][n][3]} + b1);
-                if (relu) { pk.x = relu_pk_bf16(pk.x); pk.y = relu_pk_bf16(pk.y); }
-                *(uint2*)(cell + m * 16 * HALO_STRIDE) = pk;
-            }
+        for (int m = 0; m < MT; m++) {
+            const f32x4 o0 = acc[m][0] + b[0], o1 = acc[m][1] + b[1];
+            uint32_t a0 = max_pk_i16(cvt_pk_bf16((f32x2){o0[0], o0[1]}), floor_pk);
+            uint32_t a1 = max_pk_i16(cvt_pk_bf16((f32x2){o0[2], o0[3]}), floor_pk);
+            uint32_t c0 = max_pk_i16(cvt_pk_bf16((f32x2){o1[0], o1[1]}), floor_pk);
+            uint32_t c1 = max_pk_i16(cvt_pk_bf16((f32x2){o1[2], o1[3]}), floor_pk);
+            swap16(a0, c0);
+            swap16(a1, c1);
+            if (l15 < 14) *(uint4*)(cell + m * 16 * HALO_STRIDE) = make_uint4(a0, a1, c0, c1);
         }
     }
     lds_barrier();
@@ -357,14 +373,219 @@ __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The two-image form of the fused kernel (SOLO, see resblock_tiles_kernel): its own staging and epilogues.
+// Same arithmetic, same order of the fp32 additions and same rounding points as the one-image form and
+// as vqa_conv_tiles: the two forms and the separate launches agree bit for bit.
+// ---------------------------------------------------------------------------------------------
+
+// accumulators + bias [+ the map `xres` in LDS: the residual connection] -> bf16 -> [ReLU] -> interior of the
+// image `img`; then, after a barrier, a row-wise pass applies an optional mask (KEEP: and rewrites the image,
+// a convolution reads it next) and stores the map to `dst` in 16-byte pieces.
+// A lane's accumulators are 4 channels of each of the wave's two 16-channel blocks, 8 bytes each, and
+// 8-byte LDS accesses at this position stride are 4-way bank conflicts.  One register swap per packed
+// pair between the lane rows (swap16) leaves every lane with 8 consecutive channels of its pixel -
+// channels 32 wave + 16 (row & 1) + 8 (row >> 1) .. + 7 - i.e. one conflict-free 16-byte access; the
+// residual map is read the same way and swapped back into the accumulator layout.
+// No barrier in front of the writes: `img` is an image nobody reads at this point (the caller's rule).
+template <bool MASK, bool RES, bool KEEP>
+__device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, const f32x4 (&acc)[MT][2], const f32x4 (&b)[2],
+                                                bool relu, const char* mask, char* dst, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int x = tid >> 4, pc = tid & 15;
+    const bool active = x < 14;
+    const int goff = (active ? x : 0) * 256 + pc * 16;
+    // (asked for here, not in front of the K loop - measured: with 14 more loads in flight and 56 more
+    // registers live the K loops of a tile lose 7 k cycles, the epilogues gain 2 k)
+    uint4 mv[14];
+    if (MASK) {
+#pragma unroll
+        for (int y = 0; y < 14; y++) mv[y] = *(const uint4*)(mask + goff + y * 14 * 256);
+    }
+    {
+        // ReLU without a branch per row: a signed 16-bit maximum with 0, or with the most negative value (no change)
+        const uint32_t floor_pk = relu ? 0u : 0x80008000u;
+        // lanes 14 and 15 of a row stand on the zero border: they read it (zeros) but never write
+        const int celloff = (16 + l15 + 1) * HALO_STRIDE + (wave * 32 + 16 * (lq & 1) + 8 * (lq >> 1)) * 2;
+        char* cell = img + celloff;
+        // the residual cells are read three image rows ahead (all 14 at once: 56 registers too many next to
+        // the mask rows); the order is pinned row by row, or the scheduler hoists every read to the top
+        uint4 xr[MT];
+        if (RES) {
+#pragma unroll
+            for (int m = 0; m < 3; m++) xr[m] = *(const uint4*)(xres + celloff + m * 16 * HALO_STRIDE);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            if (RES && m + 3 < MT) xr[m + 3] = *(const uint4*)(xres + celloff + (m + 3) * 16 * HALO_STRIDE);
+            f32x4 o0 = acc[m][0] + b[0], o1 = acc[m][1] + b[1];
+            if (RES) {
+                swap16(xr[m].x, xr[m].z);
+                swap16(xr[m].y, xr[m].w);
+                const f32x2 r0 = unpack_pk_bf16(xr[m].x), r1 = unpack_pk_bf16(xr[m].y);
+                const f32x2 r2 = unpack_pk_bf16(xr[m].z), r3 = unpack_pk_bf16(xr[m].w);
+                o0 += (f32x4){r0[0], r0[1], r1[0], r1[1]};
+                o1 += (f32x4){r2[0], r2[1], r3[0], r3[1]};
+            }
+            uint32_t a0 = max_pk_i16(cvt_pk_bf16((f32x2){o0[0], o0[1]}), floor_pk);
+            uint32_t a1 = max_pk_i16(cvt_pk_bf16((f32x2){o0[2], o0[3]}), floor_pk);
+            uint32_t c0 = max_pk_i16(cvt_pk_bf16((f32x2){o1[0], o1[1]}), floor_pk);
+            uint32_t c1 = max_pk_i16(cvt_pk_bf16((f32x2){o1[2], o1[3]}), floor_pk);
+            swap16(a0, c0);
+            swap16(a1, c1);
+            if (l15 < 14) *(uint4*)(cell + m * 16 * HALO_STRIDE) = make_uint4(a0, a1, c0, c1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    lds_barrier();
+    if (active) {
+        char* cell = img + (16 + x + 1) * HALO_STRIDE + pc * 16;
+#pragma unroll
+        for (int y = 0; y < 14; y++) {
+            uint4 v = *(uint4*)(cell + y * 16 * HALO_STRIDE);
+            if (MASK) {
+                v = make_uint4(mask_pk_bf16(v.x, mv[y].x), mask_pk_bf16(v.y, mv[y].y), mask_pk_bf16(v.z, mv[y].z),
+                               mask_pk_bf16(v.w, mv[y].w));
+                if (KEEP) *(uint4*)(cell + y * 16 * HALO_STRIDE) = v;
+            }
+            *(uint4*)(dst + goff + y * 14 * 256) = v;
+        }
+    }
+    if (MASK && KEEP) lds_barrier();      // the rewritten rows are other threads' fragment reads
+}
+
+template <bool RES, bool KEEP>
+__device__ __forceinline__ void solo_epilogue(char* img, const char* xres, const f32x4 (&acc)[MT][2], const f32x4 (&b)[2],
+                                              bool relu, const char* mask, char* dst, int tid) {
+    if (mask) solo_epilogue_t<true, RES, KEEP>(img, xres, acc, b, relu, mask, dst, tid);
+    else solo_epilogue_t<false, RES, KEEP>(img, xres, acc, b, relu, mask, dst, tid);
+}
+
 // RANGE false: one tile per workgroup, entry blockIdx.x of the list in XCD order.  RANGE true: the
 // tile range is in device memory (`level_info`: first tile, tiles) and the workgroups of the launch,
 // however many, share it; every workgroup leaves its loop, with or without work.
-template <bool RANGE>
-__global__ __launch_bounds__(256, 2) void resblock_tiles_kernel(vqa_resblock_params p) {
+// SOLO: for launches of at most one workgroup per CU.  A workgroup then takes the LDS and the registers of
+// two: a second halo image, and 512 registers per lane (the accumulators move to the accumulation
+// registers).  The body's input stays in the first image, the intermediate map goes to the second, the
+// result to the first again: every map is written into an image that nobody is reading (no barrier in
+// front of the writes), the residual connection is read from LDS (not from memory), the three biases and
+// all 14 rows of the source map are asked for at entry, and the epilogues write LDS without bank conflicts
+// (solo_epilogue_t).  Fixed image addresses: chosen at run time they cost a vector add per LDS read in the
+// K loops, which is why the sources of a 1x1 pass in front are staged into the second image.
+template <bool RANGE, bool SOLO>
+__global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_resblock_params p) {
     extern __shared__ __attribute__((aligned(16))) char halo[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
+    if constexpr (SOLO) {
+        static_assert(!RANGE, "the two-image form takes one tile per workgroup");
+        const vqa_resblock_tile t = p.tiles[xcd_tile_index(blockIdx.x, p.num_tiles)];
+        unsigned long long* stamps = p.phase_stamps ? p.phase_stamps + (int64_t)blockIdx.x * 8 : nullptr;
+#define STAMP(i) if (stamps && tid == 0) stamps[i] = __builtin_readcyclecounter()
+        STAMP(0);
+        const int64_t slot_b = p.slot_stride * 2;
+        char* arena = (char*)p.arena;
+        const bool relu = (p.flags & VQA_CONV_RELU) != 0, has_bias = (p.flags & VQA_CONV_BIAS) != 0;
+        const int64_t wstep = 8 * 1024;
+        const int64_t wlane = (int64_t)(wave * 2) * 1024 + lane * 16;
+        const int64_t w33 = (int64_t)t.wgroup * p.w_group_stride * 2 + wlane;
+        const bool pre2 = t.src1 >= 0, pre1 = t.pre_group >= 0;
+        int64_t wstep_pre = wstep;
+        const char* wbase = (const char*)p.w_first + w33;
+        if (pre2) wbase = (const char*)p.w_pre + (int64_t)t.wgroup * p.w_pre_group_stride * 2 + wlane;
+        else if (pre1) {
+            wbase = (const char*)p.w_pre + (int64_t)(t.pre_group >> 1) * p.w_pre_group_stride * 2 + (t.pre_group & 1) * wstep + wlane;
+            wstep_pre = 2 * wstep;
+        }
+        // (the second image is beyond the reach of the LDS instructions' 16-bit offsets from the first image's
+        // lane address: its own lane address, opaque to constant folding, keeps the K loops' reads free of adds.
+        // Made here: a volatile statement between the two halves of the staging below sends its 14 rows through scratch)
+        int lane2 = l15 * HALO_STRIDE + lq * 16 + HALO_BYTES;
+        asm volatile("" : "+v"(lane2));
+        bf16x8 wr[4][2];
+        load_wring(wr, wbase, wstep_pre);
+        f32x4 b_pre[2], b_first[2], b_second[2];
+        lane_bias(b_pre, (pre2 && has_bias) ? p.bias_pre + (int64_t)t.wgroup * 128 : nullptr, wave, lq);
+        lane_bias(b_first, has_bias ? p.bias_first + (int64_t)t.wgroup * 128 : nullptr, wave, lq);
+        lane_bias(b_second, has_bias ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr, wave, lq);
+        char* const img2 = halo + HALO_BYTES;
+        f32x4 acc[MT][2];
+        int xaddr[MT], xaddr2[MT];
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
+            xaddr2[m] = m * 16 * HALO_STRIDE + lane2;
+        }
+        // halo_stage with all 14 rows of the source map in flight at once (one memory latency instead of two).
+        // Named values, not an array (any statement the compiler cannot see through between an array's
+        // writes and reads sends it through scratch), and a scheduler barrier that keeps the loads together
+        // (left alone they are paired off with their writes, one exposed latency each).  The threads of the
+        // two idle image columns write into the 32 unused bytes behind a position's 256: no branch.
+        {
+            const int sx = tid >> 4, spc = tid & 15;
+            const char* g = arena + (int64_t)t.src0 * slot_b + (sx < 14 ? sx : 0) * 256 + spc * 16;
+            char* cell = ((pre2 || pre1) ? img2 : halo) +
+                         (sx < 14 ? (16 + sx + 1) * HALO_STRIDE + spc * 16 : 17 * HALO_STRIDE + 256 + (spc & 1) * 16);
+#define SOLO_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#define SOLO_ASK(i) const uint4 st##i = *(const uint4*)(g + i * 14 * 256);
+#define SOLO_PUT(i) *(uint4*)(cell + i * 16 * HALO_STRIDE) = st##i;
+            SOLO_ROWS(SOLO_ASK)
+            __builtin_amdgcn_sched_barrier(0);
+            // the borders of both images, cleared under that latency (straight-line code: the last round repeats
+            // writes of zeros instead of branching - across a branch the compiler sinks the loads to their uses)
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = min(tid + 256 * k, 68 * 16 - 1), j = idx >> 4;
+            const int pos = j < 16 ? j : (j < 44 ? (((j - 16) >> 1) + 1) * 16 + ((j & 1) ? 15 : 0) : 240 + (j - 44));
+            *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(img2 + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+        }
+            __builtin_amdgcn_sched_barrier(0);
+            SOLO_ROWS(SOLO_PUT)
+#undef SOLO_ROWS
+#undef SOLO_ASK
+#undef SOLO_PUT
+        }
+        __syncthreads();
+        STAMP(1);
+        int s = 0;
+        if (pre2 || pre1) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            const int nsteps_pre = pre2 ? 8 : 4;
+#pragma unroll 1
+            for (int c = 0; c < (pre2 ? 2 : 1); c++) {
+                if (c) {
+                    __syncthreads();
+                    halo_stage(img2, arena + (int64_t)t.src1 * slot_b, 256, tid, false);
+                    __syncthreads();
+                }
+                conv_kloop<1, false>(halo, xaddr2, wbase, wstep_pre, nsteps_pre, s, wr, acc, false);
+            }
+            wbase = (const char*)p.w_first + w33;
+            load_wring(wr, wbase, wstep);
+            solo_epilogue<false, true>(halo, nullptr, acc, b_pre, pre2 && relu, t.pre_mask >= 0 ? arena + (int64_t)t.pre_mask * slot_b : nullptr,
+                                       arena + (int64_t)t.res * slot_b, tid);
+            s = 0;
+        }
+        STAMP(2);
+        conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+        STAMP(3);
+        wbase = (const char*)p.w_second + w33;
+        load_wring(wr, wbase, wstep);
+        // (every wave is past the 1x1 pass's reads of the second image: the barrier of that pass's epilogue)
+        solo_epilogue<false, true>(img2, nullptr, acc, b_first, relu, t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
+        s = 0;
+        STAMP(4);
+        conv_kloop<9, true>(halo, xaddr2, wbase, wstep, 36, s, wr, acc, false);
+        STAMP(5);
+        // the result goes where the input is: each wave reads its own cells of it first, nobody else reads it
+        if (t.res >= 0) solo_epilogue<true, false>(halo, halo, acc, b_second, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
+        else solo_epilogue<false, false>(halo, nullptr, acc, b_second, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
+        STAMP(6);
+#undef STAMP
+        return;
+    }
     int tile_i = RANGE ? p.level_info[0] + (int)blockIdx.x : xcd_tile_index(blockIdx.x, p.num_tiles);
     const int tile_end = RANGE ? p.level_info[0] + p.level_info[1] : 0;
     if (RANGE && tile_i >= tile_end) return;
@@ -480,15 +701,19 @@ extern "C" int vqa_resblock_tiles(const vqa_resblock_params* p, void* stream) {
         return VQA_EINVAL;
     }
     if (p->num_tiles == 0) return VQA_OK;
-    if (!vqa_allow_lds((const void*)resblock_tiles_kernel<false>, CONV_LDS, "vqa_resblock_tiles") ||
-        !vqa_allow_lds((const void*)resblock_tiles_kernel<true>, CONV_LDS, "vqa_resblock_tiles")) return VQA_ELAUNCH;
+    if (!vqa_allow_lds((const void*)resblock_tiles_kernel<false, false>, CONV_LDS, "vqa_resblock_tiles") ||
+        !vqa_allow_lds((const void*)resblock_tiles_kernel<true, false>, CONV_LDS, "vqa_resblock_tiles") ||
+        !vqa_allow_lds((const void*)resblock_tiles_kernel<false, true>, 2 * CONV_LDS, "vqa_resblock_tiles")) return VQA_ELAUNCH;
+    // a launch that cannot put two workgroups on any CU gives each workgroup the LDS and registers of two
+    const bool solo = !p->level_info && p->num_tiles <= vqa_cu_count();
     // two 3x3 convolutions of 128 -> 128 channels per tile, plus the 1x1 passes in front: K = 256 per
     // forward binary node, K = 128 per backward child of one (num_pre counts K = 256 equivalents)
     VqaProfScope prof(VQA_K_RESBLOCK, 2.0 * 2.0 * VQA_HW * 1152.0 * 128.0 * p->num_tiles +
                                           2.0 * VQA_HW * 256.0 * 128.0 * p->num_pre,
                       (double)p->num_tiles * VQA_HW * 2.0 * 128 * 3, (hipStream_t)stream);
-    if (p->level_info) hipLaunchKernelGGL(resblock_tiles_kernel<true>, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(resblock_tiles_kernel<false>, dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
+    if (p->level_info) hipLaunchKernelGGL((resblock_tiles_kernel<true, false>), dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
+    else if (solo) hipLaunchKernelGGL((resblock_tiles_kernel<false, true>), dim3(p->num_tiles), dim3(256), 2 * CONV_LDS, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((resblock_tiles_kernel<false, false>), dim3(p->num_tiles), dim3(256), CONV_LDS, (hipStream_t)stream, *p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { vqa_set_error(std::string("vqa_resblock_tiles: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
     return VQA_OK;

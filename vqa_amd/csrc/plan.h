@@ -49,3 +49,4 @@ void vqa_set_error(const std::string& s);
 // Raises a kernel's dynamic-LDS limit on the current device: once per (kernel, device), callable from
 // several threads.  False, with the error message set, if HIP refuses.
 bool vqa_allow_lds(const void* kernel, int bytes, const char* who);
+int vqa_cu_count();

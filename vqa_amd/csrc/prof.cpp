@@ -67,6 +67,21 @@ extern "C" int vqa_prof_collect(double* out, int32_t kinds) {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per (kernel, device).  A kernel's code object
 // is loaded per device, so the limit is raised on each device the library is used on.
+// Compute units of the current device (asked once per device; 0 if the runtime will not say).
+int vqa_cu_count() {
+    static std::mutex mu;
+    static std::vector<std::pair<int, int>> known;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& k : known)
+        if (k.first == dev) return k.second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    known.emplace_back(dev, n);
+    return n;
+}
+
 bool vqa_allow_lds(const void* kernel, int bytes, const char* who) {
     static std::mutex mu;
     static std::vector<std::pair<const void*, int>> done;

@@ -33,6 +33,10 @@ __device__ __forceinline__ uint32_t relu_pk_bf16(uint32_t v) {
     const s16x2 z = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
 }
+// signed 16-bit maximum of each half with the matching half of `lim`
+__device__ __forceinline__ uint32_t max_pk_i16(uint32_t v, uint32_t lim) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), __builtin_bit_cast(s16x2, lim)));
+}
 // v * (m > 0) per bf16 of a packed pair, as a bit mask: max(m, 0) clears negatives and -0, then
 // (0 - m) >> 15 (arithmetic) is all ones exactly where m was positive.  Inline asm because the
 // compiler rewrites any C form of this into per-half compares, selects and a permute.
