@@ -53,6 +53,7 @@ def parse():
                          "all-reduces that gradient and updates the whole layer - the path with the most multi-rank coverage")
     ap.add_argument('--dp-replicated-update', action='store_true', help='the default; accepted for older command lines')
     ap.add_argument('--no-fwd-bwd-only', action='store_true', help='skip the extra steps without the optimizer that give executor_fwd_bwd')
+    ap.add_argument('--torch-loss', action='store_true', help='torch.nn.CrossEntropyLoss (seven launches) instead of vqa_amd.loss.CrossEntropyLoss (one)')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of vqa_amd.optim.FusedAdam")
     ap.add_argument('--cpu-programs', action='store_true', help='hand the programs over as host tensors (the data loader\'s), '
                     'so that the tile lists of a step are built while the device still runs the step before')
@@ -207,7 +208,12 @@ def main():
         else:
             from vqa_amd.optim import FusedAdam
             opt = FusedAdam(net.parameters(), lr=1e-4, weight_decay=5e-5, executor=net)
-    loss_fn = torch.nn.CrossEntropyLoss()
+    # Train_model.py:185: CrossEntropyLoss, mean over the batch
+    if a.torch_loss:
+        loss_fn = torch.nn.CrossEntropyLoss()
+    else:
+        from vqa_amd.loss import CrossEntropyLoss
+        loss_fn = CrossEntropyLoss()
 
     # resident synthetic batches (seed = 1000*config + rank, config 3)
     batches, flops_step, flops_exec_step, nodes_step = [], [], [], []

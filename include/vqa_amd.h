@@ -429,6 +429,31 @@ int vqa_bias_act(const float* acc, const float* bias, void* out, int32_t rows, i
 /* out[col] += sum over rows of x[row][col]; x bf16 (is_bf16) or fp32 */
 int vqa_col_sum(const void* x, float* out, int32_t rows, int32_t cols, int64_t ld, int32_t is_bf16,
                 void* stream);
+/* ------------------------------------------------------------------------------------------
+ * The classifier's last linear layer and the loss behind it, in few launches (their cost is
+ * launches, not arithmetic).  Replaces nn.Linear(fc, num_answers) of Module_Model.py:92 and
+ * autograd's gradients of it, and torch.nn.CrossEntropyLoss of Train_model.py:185,312.
+ * Operands are bf16 where the GEMM path has bf16 (act [N][ld_act], w [A][ld_w], the gradient of
+ * the logits is rounded on the way in); sums are fp32 in a fixed order.  A <= 64, F % 64 == 0.
+ * ------------------------------------------------------------------------------------------ */
+/* logits[n][o] = sum_i act[n][i] * w[o][i] + bias[o]   (fp32 [N][A]; bias may be null) */
+int vqa_head_forward(const void* act, int64_t ld_act, const void* w, int64_t ld_w, const float* bias,
+                     float* logits, int32_t N, int32_t F, int32_t A, void* stream);
+/* floats of workspace vqa_head_backward needs */
+int64_t vqa_head_backward_workspace(int32_t N, int32_t F, int32_t A);
+/* From dlogits fp32 [N][A]: gin bf16 [N][ld_gin] = (dlogits x w) * (act > 0), the gradient into the
+ * layer's input times the ReLU that produced it; dw fp32 [A][F], db fp32 [A] (this layer's weight and
+ * bias gradients) and db_in fp32 [F] = column sums of gin (the bias gradient of the layer in front).
+ * All four are written whole. */
+int vqa_head_backward(const float* dlogits, const void* act, int64_t ld_act, const void* w, int64_t ld_w,
+                      void* gin, int64_t ld_gin, float* dw, float* db_in, float* db, float* workspace,
+                      int32_t N, int32_t F, int32_t A, void* stream);
+/* loss[0] = mean over n of (logsumexp(logits[n]) - logits[n][target[n]]) and its gradient
+ * dlogits = (softmax(logits) - onehot(target)) / N, fp32 [N][A], in one launch; targets int64 in
+ * [0, A) (a row whose target is out of range adds nothing to either) */
+int vqa_xent(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t N, int32_t A,
+             void* stream);
+
 /* dst slot <- (sum of listed source slots) * (mask slot > 0): scene-node gradient fan-in
  * (feats[i:i+1] is read by every scene node of sample i, Module_Model.py:214) */
 int vqa_slot_sum_mask(void* arena, const int32_t* offsets, const int32_t* src_slots,

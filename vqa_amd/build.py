@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libvqa_amd.so')
-SOURCES = ['schedule.cpp', 'tree.cpp', 'prof.cpp', 'feed.cpp', 'conv.hip', 'conv_f32.hip', 'wgrad.hip', 'gemm.hip', 'misc.hip', 'adam.hip', 'devsched.hip']
+SOURCES = ['schedule.cpp', 'tree.cpp', 'prof.cpp', 'feed.cpp', 'conv.hip', 'conv_f32.hip', 'wgrad.hip', 'gemm.hip', 'misc.hip', 'adam.hip', 'devsched.hip', 'head.hip']
 HEADERS = ['vqa_dev.h', 'plan.h', 'prof.h', os.path.join('..', '..', 'include', 'vqa_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-unused-function']

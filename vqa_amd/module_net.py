@@ -181,6 +181,10 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
         # module width 128: both convolutions of a residual body run in one kernel; False selects
         # the two-launch path (bit-identical results)
         self.fuse_residual_body = True
+        # the last linear layer (a hidden layer in front of it, at most 64 answers) forward in one launch and
+        # backward in two (vqa_head_forward / vqa_head_backward) instead of GEMM + bias and cast + column sum +
+        # two GEMMs + column sum; False selects those (same operands, sums in another order)
+        self.fuse_head = True
         # run nodes that have slack in later tree levels so that launches fill whole rounds of the device
         # (training calls only: in a forward-only call the device waits for the tile lists, and the
         # list scheduling costs the host more than the evener launches give back - 11 % of the call
@@ -608,6 +612,11 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
             else:
                 tiles = (np128 // 128) * (_rup(fo, 128) // 128)
                 split = max(1, min(prev_dim // 64, 16, -(-512 // tiles)))
+            if last and self._head_fused(fcs, [HW * p_] + list(d['fcs'])):
+                logits = torch.empty(N, fo, dtype=torch.float32, device=dev)
+                ops.head_forward(acts[-1], prev_dim, pk['fc_w'][li], prev_dim, lin.bias.detach(), logits, N, prev_dim, fo)
+                st['logits'] = logits
+                break
             acc = ws.get('fc_acc%d' % li, split * N * fo, torch.float32, dev)
             ops.gemm(acts[-1], pk['fc_w'][li], acc, N, fo, prev_dim, lda=prev_dim, ldb=prev_dim, ldc=fo,
                      split_k=split)
@@ -636,6 +645,11 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
         if self.keep_state:
             self.last_state = st
         return st
+
+    def _head_fused(self, fcs, dims_in):
+        """Whether the last linear layer runs as vqa_head_forward / vqa_head_backward."""
+        return (self.fuse_head and len(fcs) >= 2 and fcs[-1] <= 64 and dims_in[-1] % 64 == 0 and
+                dims_in[-1] <= 8192)
 
     def _device_schedule_buffers(self, ws, N, T, dev):
         """Workspace of vqa_devsched_build for N programs of T tokens, the arity table on the device,
@@ -768,14 +782,34 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
         emitted = set()
 
         # ---- linear layers, last to first
-        g = ws.get('dlog', np128 * d['na_pad'], torch.bfloat16, dev)
         dl = dlogits.detach().to(torch.float32).contiguous()
-        ops.cast_pad(dl, g, N, d['na'], np128, d['na_pad'])
-        gb = torch.zeros(d['na'], **f32)
-        ops.col_sum(dl, gb, N, d['na'], d['na'])
-        grads['classifier.%d.bias' % self._fc_idx[-1]] = gb
-        g_ld = d['na_pad']
-        for li in range(len(fcs) - 1, -1, -1):
+        li_first = len(fcs) - 1
+        if self._head_fused(fcs, dims_in):
+            # the last layer, and the bias gradient of the layer in front of it, in two launches
+            li = li_first
+            fo, fi = fcs[li], dims_in[li]
+            name = 'classifier.%d' % self._fc_idx[li]
+            gw, gb, gb_in = torch.empty(fo, fi, **f32), torch.empty(fo, **f32), torch.empty(fi, **f32)
+            gin = ws.get('fc_gin%d' % li, np128 * fi, torch.bfloat16, dev)
+            if np128 != N:
+                gin.view(np128, fi)[N:].zero_()   # rows past N are the K padding of the next GEMM
+            wk = ws.get('head_ws', ops.head_backward_workspace(N, fi, fo), torch.float32, dev)
+            ops.head_backward(dl, acts[li], fi, pk['fc_w'][li], fi, gin, fi, gw, gb_in, gb, wk, N, fi, fo)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(name + '.weight', gw)
+                emitted.add(name + '.weight')
+            grads[name + '.weight'], grads[name + '.bias'] = gw, gb
+            grads['classifier.%d.bias' % self._fc_idx[li - 1]] = gb_in
+            g, g_ld = gin, fi
+            li_first = li - 1
+        else:
+            g = ws.get('dlog', np128 * d['na_pad'], torch.bfloat16, dev)
+            ops.cast_pad(dl, g, N, d['na'], np128, d['na_pad'])
+            gb = torch.zeros(d['na'], **f32)
+            ops.col_sum(dl, gb, N, d['na'], d['na'])
+            grads['classifier.%d.bias' % self._fc_idx[-1]] = gb
+            g_ld = d['na_pad']
+        for li in range(li_first, -1, -1):
             fo, fi = fcs[li], dims_in[li]
             name = 'classifier.%d' % self._fc_idx[li]
             # weight gradient: dW[fo][fi] = g^T (rows = samples) x input activations
@@ -819,7 +853,7 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
         # ---- classifier conv1x1: weight/bias gradient, and the gradient into the roots' dZ slots
         it_off, it_cnt = plan.section('SAMPLE_ITEMS')
         sec = lambda n: (blob, plan.section(n)[0])
-        gcb = torch.zeros(p_, **f32)
+        gcb = torch.empty(p_, **f32)       # (written whole by the reduction)
         info = plan.info
         # partial blocks of the largest launch, with one row of bias sums per item behind them: every
         # gradient is summed in item order, the same bits on every run
@@ -898,7 +932,7 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
         self._conv(st, arena, arena, pk['wd_stem1'], 'STEM1_DGRAD_TILES', 9, c // 128, c, slot, slot, mask=arena)
         if want_dx:
             self._input_grad(st, False)
-        gs1b, gs0b = torch.zeros(c, **f32), torch.zeros(c, **f32)
+        gs1b, gs0b = torch.empty(c, **f32), torch.empty(c, **f32)       # (written whole by the reductions)
         fi_off, fi_cnt = plan.section('SAMPLE_ITEMS_FINE')
         ops.wgrad_tiles(arena, arena, (blob, fi_off), fi_cnt, sec('SLOTS_S0'), sec('SLOTS_DF'), None, gs1b,
                         taps=9, k_chunks=c // 128, n_out=c, src_slot_stride=HW * c, dy_slot_stride=HW * c,

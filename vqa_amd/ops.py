@@ -272,6 +272,39 @@ def col_sum(x, out, rows, cols, ld):
                                        int(x.dtype == torch.bfloat16), _stream()))
 
 
+def head_forward(act, ld_act, w, ld_w, bias, logits, n, f, a):
+    """logits fp32 [n][a] = act bf16 [n][ld_act] x w bf16 [a][ld_w]^T + bias: the classifier's last linear
+    layer (Module_Model.py:92) in one launch"""
+    assert act.dtype == w.dtype == torch.bfloat16 and logits.dtype == torch.float32 and logits.is_contiguous()
+    assert act.numel() >= (n - 1) * ld_act + f and w.numel() >= (a - 1) * ld_w + f and logits.numel() >= n * a
+    _lib.check(_lib.load().vqa_head_forward(_ptr(act), ld_act, _ptr(w), ld_w, _ptr(bias), _ptr(logits), n, f, a, _stream()))
+
+
+def head_backward_workspace(n, f, a):
+    return int(_lib.load().vqa_head_backward_workspace(n, f, a))
+
+
+def head_backward(dlogits, act, ld_act, w, ld_w, gin, ld_gin, dw, db_in, db, workspace, n, f, a):
+    """Backward of head_forward: gin bf16 [n][ld_gin] (times act > 0), dw fp32 [a][f], db fp32 [a], and
+    db_in fp32 [f] = column sums of gin; two launches"""
+    assert dlogits.dtype == dw.dtype == db_in.dtype == db.dtype == workspace.dtype == torch.float32
+    assert act.dtype == w.dtype == gin.dtype == torch.bfloat16 and dlogits.is_contiguous()
+    assert dlogits.numel() >= n * a and act.numel() >= (n - 1) * ld_act + f and w.numel() >= (a - 1) * ld_w + f
+    assert gin.numel() >= (n - 1) * ld_gin + f and dw.numel() >= a * f and db_in.numel() >= f and db.numel() >= a
+    assert workspace.numel() >= head_backward_workspace(n, f, a)
+    _lib.check(_lib.load().vqa_head_backward(_ptr(dlogits), _ptr(act), ld_act, _ptr(w), ld_w, _ptr(gin), ld_gin, _ptr(dw),
+                                             _ptr(db_in), _ptr(db), _ptr(workspace), n, f, a, _stream()))
+
+
+def xent(logits, target, loss, dlogits):
+    """Mean cross-entropy of fp32 logits [n][a] against int64 targets, and its gradient, in one launch"""
+    n, a = logits.shape
+    assert logits.dtype == dlogits.dtype == loss.dtype == torch.float32 and target.dtype == torch.int64
+    assert logits.is_contiguous() and dlogits.is_contiguous() and target.is_contiguous()
+    assert target.numel() == n and dlogits.numel() == n * a and loss.numel() >= 1
+    _lib.check(_lib.load().vqa_xent(_ptr(logits), _ptr(target), _ptr(loss), _ptr(dlogits), n, a, _stream()))
+
+
 def slot_sum_mask(arena, blob, off_offsets, off_src, off_dst, off_mask, n_dst, slot_elems):
     b = blob.data_ptr()
     _lib.check(_lib.load().vqa_slot_sum_mask(_ptr(arena), C.c_void_p(b + 4 * off_offsets),
