@@ -82,10 +82,12 @@ __device__ __forceinline__ void halo_stage(char* halo, const char* sp, int pix_s
 // so three K-steps of MFMAs cover the L2 latency); pixel fragments through an 8-deep ring read 7
 // tiles ahead; the issue order is pinned to 1 LDS read : 2 MFMA (left alone, the scheduler collapses
 // the ring and waits on every read right after issuing it).  With ZERO the accumulators start from
-// the first K-step's products (C operand = inline 0) instead of from registers somebody cleared.
+// the first K-step's products plus `c0` (the C operand of those MFMAs: this lane's bias values, or zeros)
+// instead of from registers somebody cleared - the bias costs no instruction of its own anywhere.
 template <int TAPS, bool ZERO>
 __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[MT], const char* wbase, int64_t wstep,
-                                           int nsteps, int& s, bf16x8 (&wr)[4][2], f32x4 (&acc)[MT][2], bool diag_now) {
+                                           int nsteps, int& s, bf16x8 (&wr)[4][2], f32x4 (&acc)[MT][2],
+                                           const f32x4 (&c0)[2], bool diag_now) {
     bf16x8 xq[8];
     {
         const char* x0 = halo + ((TAPS == 9) ? 0 : 17) * HALO_STRIDE;
@@ -108,9 +110,8 @@ __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[
                 const int ka = (qa / MT) & 3, ma = qa % MT;
                 xq[qa & 7] = *(const bf16x8*)((qa < 4 * MT ? xb : xn) + xaddr[ma] + ka * 64);
                 if (FIRST && ks == 0) {
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    acc[m][0] = mma16(wr[ks][0], xq[q & 7], z);
-                    acc[m][1] = mma16(wr[ks][1], xq[q & 7], z);
+                    acc[m][0] = mma16(wr[ks][0], xq[q & 7], c0[0]);
+                    acc[m][1] = mma16(wr[ks][1], xq[q & 7], c0[1]);
                 } else {
                     acc[m][0] = mma16(wr[ks][0], xq[q & 7], acc[m][0]);
                     acc[m][1] = mma16(wr[ks][1], xq[q & 7], acc[m][1]);
@@ -136,17 +137,15 @@ __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[
 // cache lines per instruction; written, or worse read (residual, mask), that way the epilogue costs
 // more than the K loop.  So the raw accumulators go through LDS (fp32, 7 image rows at a time, the
 // halo image is dead by now) and come back pixel-major: every global access is 16 bytes per lane,
-// 1 KiB contiguous per wave, and bias, residual, rounding, ReLU and mask are applied there, two
-// channels per instruction.   out = [relu]( acc + bias + res ) * (mask > 0)
+// 1 KiB contiguous per wave, and residual, rounding, ReLU and mask are applied there, two
+// channels per instruction (the bias is in the accumulators since the first K-step).
+//   out = [relu]( acc + res ) * (mask > 0)
 template <bool RES, bool MASK>
-__device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+__device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[MT][2], bool relu,
                                                 const char* rsrc, const char* msrc, char* dptr, int pix_stride,
                                                 int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     const int pc = tid & 15;            // this thread's 16-byte column of every row: channels 8*pc..8*pc+7
-    f32x2 bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) bv[j] = bias ? *(const f32x2*)(bias + pc * 8 + 2 * j) : (f32x2){0.f, 0.f};
     float* stg = (float*)halo;          // [98 pixels][132 floats]: 528-byte rows keep the writes conflict-free
     // (a generic lambda called with a constant: a run-time `half` would select between accumulator
     // registers with one v_cndmask per value)
@@ -183,7 +182,6 @@ __device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[M
                 if (MASK) { k[0] = mv[i].x; k[1] = mv[i].y; k[2] = mv[i].z; k[3] = mv[i].w; }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    o[j] += bv[j];
                     if (RES) o[j] += unpack_pk_bf16(r[j]);
                     w[j] = cvt_pk_bf16(o[j]);
                     if (relu) w[j] = relu_pk_bf16(w[j]);
@@ -199,16 +197,24 @@ __device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[M
 
 // one specialisation per combination: a residual or mask array that only some paths fill makes the
 // compiler carry placeholders for the others through the whole kernel (scalar-register spills)
-__device__ __forceinline__ void conv_epilogue(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+__device__ __forceinline__ void conv_epilogue(char* halo, const f32x4 (&acc)[MT][2], bool relu,
                                               const char* rsrc, const char* msrc, char* dptr, int pix_stride,
                                               int tid) {
     if (rsrc) {
-        if (msrc) conv_epilogue_t<true, true>(halo, acc, bias, relu, rsrc, msrc, dptr, pix_stride, tid);
-        else conv_epilogue_t<true, false>(halo, acc, bias, relu, rsrc, msrc, dptr, pix_stride, tid);
+        if (msrc) conv_epilogue_t<true, true>(halo, acc, relu, rsrc, msrc, dptr, pix_stride, tid);
+        else conv_epilogue_t<true, false>(halo, acc, relu, rsrc, msrc, dptr, pix_stride, tid);
     } else {
-        if (msrc) conv_epilogue_t<false, true>(halo, acc, bias, relu, rsrc, msrc, dptr, pix_stride, tid);
-        else conv_epilogue_t<false, false>(halo, acc, bias, relu, rsrc, msrc, dptr, pix_stride, tid);
+        if (msrc) conv_epilogue_t<false, true>(halo, acc, relu, rsrc, msrc, dptr, pix_stride, tid);
+        else conv_epilogue_t<false, false>(halo, acc, relu, rsrc, msrc, dptr, pix_stride, tid);
     }
+}
+
+// this lane's bias values: 4 channels of each of the wave's two 16-channel blocks (zeros without a bias),
+// in the accumulator layout: they are the C operand of the first K-step's MFMAs
+__device__ __forceinline__ void lane_bias(f32x4 (&b)[2], const float* bias, int wave, int lq) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    b[0] = b[1] = z;
+    if (bias) { b[0] = *(const f32x4*)(bias + wave * 32 + lq * 4); b[1] = *(const f32x4*)(bias + wave * 32 + lq * 4 + 16); }
 }
 
 template <int TAPS>
@@ -233,6 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         wr[i][1] = *(const bf16x8*)(wbase + i * wstep + 1024);
     }
     halo_zero_border(halo, tid);
+    f32x4 binit[2];
+    lane_bias(binit, (p.flags & VQA_CONV_BIAS) ? p.bias + (int64_t)t.wgroup * p.n_out + ntile * 128 : nullptr, wave, lq);
 
     f32x4 acc[MT][2];
     // LDS byte offset of this lane's pixel in every pixel tile, at tap (-1,-1), K-chunk lq
@@ -250,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         __syncthreads();   // every wave is done reading the previous chunk's image
         halo_stage(halo, sp, p.src_pix_stride * 2, tid, (p.flags & 0x400) != 0);
         __syncthreads();
-        if (c == 0) conv_kloop<TAPS, true>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, (p.flags & 0x200) != 0);
-        else conv_kloop<TAPS, false>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, (p.flags & 0x200) != 0);
+        if (c == 0) conv_kloop<TAPS, true>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, binit, (p.flags & 0x200) != 0);
+        else conv_kloop<TAPS, false>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, binit, (p.flags & 0x200) != 0);
     }
 
     if (p.flags & 0x100) {   // diagnostic: skip the epilogue
@@ -269,11 +277,10 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         choff = (ntile % p.pair_out) * 128;
     } else { dslot = t.dst0; mslot = t.mask0; choff = ntile * 128; }
     if (dslot < 0) return;     // uniform over the workgroup
-    const float* bias = (p.flags & VQA_CONV_BIAS) ? p.bias + (int64_t)t.wgroup * p.n_out + ntile * 128 : nullptr;
     const char* rsrc = t.res >= 0 ? (const char*)p.res + ((int64_t)t.res * p.dst_slot_stride + choff) * 2 : nullptr;
     const char* msrc = mslot >= 0 ? (const char*)p.mask + ((int64_t)mslot * p.dst_slot_stride + choff) * 2 : nullptr;
     char* dptr = (char*)p.dst + ((int64_t)dslot * p.dst_slot_stride + choff) * 2;
-    conv_epilogue(halo, acc, bias, (p.flags & VQA_CONV_RELU) != 0, rsrc, msrc, dptr, p.dst_pix_stride, tid);
+    conv_epilogue(halo, acc, (p.flags & VQA_CONV_RELU) != 0, rsrc, msrc, dptr, p.dst_pix_stride, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -298,17 +305,10 @@ __device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
     a = r[0]; b = r[1];
 }
 
-// this lane's bias values: 4 channels of each of the wave's two 16-channel blocks (zeros without a bias)
-__device__ __forceinline__ void lane_bias(f32x4 (&b)[2], const float* bias, int wave, int lq) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    b[0] = b[1] = z;
-    if (bias) { b[0] = *(const f32x4*)(bias + wave * 32 + lq * 4); b[1] = *(const f32x4*)(bias + wave * 32 + lq * 4 + 16); }
-}
-
-// accumulators (+ bias, ReLU) -> bf16 -> interior of the halo image; then a row-wise pass applies
-// an optional mask, rewrites the image and stores the map to `dst` in 16-byte pieces.
+// accumulators (the bias is in them) [ReLU] -> bf16 -> interior of the halo image; then a row-wise pass
+// applies an optional mask, rewrites the image and stores the map to `dst` in 16-byte pieces.
 template <bool MASK>
-__device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+__device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT][2], bool relu,
                                                const char* mask, char* dst, int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     // row pass mapping: thread = (image column x = tid >> 4, 16-byte piece pc = tid & 15), looping over
@@ -322,9 +322,6 @@ __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT
 #pragma unroll
         for (int y = 0; y < 14; y++) mv[y] = *(const uint4*)(mask + goff + y * 14 * 256);
     }
-    // the bias is asked for in front of the barrier (behind it the wait for it is all exposed)
-    f32x4 b[2];
-    lane_bias(b, bias, wave, lq);
     lds_barrier();          // every wave has finished reading the image
     {
         // 16-byte conflict-free LDS writes after a swap between the lane rows: see solo_epilogue_t
@@ -332,7 +329,7 @@ __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT
         char* cell = halo + (16 + l15 + 1) * HALO_STRIDE + (wave * 32 + 16 * (lq & 1) + 8 * (lq >> 1)) * 2;
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            const f32x4 o0 = acc[m][0] + b[0], o1 = acc[m][1] + b[1];
+            const f32x4 o0 = acc[m][0], o1 = acc[m][1];
             uint32_t a0 = max_pk_i16(cvt_pk_bf16((f32x2){o0[0], o0[1]}), floor_pk);
             uint32_t a1 = max_pk_i16(cvt_pk_bf16((f32x2){o0[2], o0[3]}), floor_pk);
             uint32_t c0 = max_pk_i16(cvt_pk_bf16((f32x2){o1[0], o1[1]}), floor_pk);
@@ -359,10 +356,10 @@ __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT
     lds_barrier();
 }
 
-__device__ __forceinline__ void acc_to_image(char* halo, const f32x4 (&acc)[MT][2], const float* bias, bool relu,
+__device__ __forceinline__ void acc_to_image(char* halo, const f32x4 (&acc)[MT][2], bool relu,
                                              const char* mask, char* dst, int tid) {
-    if (mask) acc_to_image_t<true>(halo, acc, bias, relu, mask, dst, tid);
-    else acc_to_image_t<false>(halo, acc, bias, relu, mask, dst, tid);
+    if (mask) acc_to_image_t<true>(halo, acc, relu, mask, dst, tid);
+    else acc_to_image_t<false>(halo, acc, relu, mask, dst, tid);
 }
 
 __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase, int64_t wstep) {
@@ -379,7 +376,7 @@ __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase
 // as vqa_conv_tiles: the two forms and the separate launches agree bit for bit.
 // ---------------------------------------------------------------------------------------------
 
-// accumulators + bias [+ the map `xres` in LDS: the residual connection] -> bf16 -> [ReLU] -> interior of the
+// accumulators (the bias is in them) [+ the map `xres` in LDS: the residual connection] -> bf16 -> [ReLU] -> interior of the
 // image `img`; then, after a barrier, a row-wise pass applies an optional mask (KEEP: and rewrites the image,
 // a convolution reads it next) and stores the map to `dst` in 16-byte pieces.
 // A lane's accumulators are 4 channels of each of the wave's two 16-channel blocks, 8 bytes each, and
@@ -389,7 +386,7 @@ __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase
 // residual map is read the same way and swapped back into the accumulator layout.
 // No barrier in front of the writes: `img` is an image nobody reads at this point (the caller's rule).
 template <bool MASK, bool RES, bool KEEP>
-__device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, const f32x4 (&acc)[MT][2], const f32x4 (&b)[2],
+__device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, const f32x4 (&acc)[MT][2],
                                                 bool relu, const char* mask, char* dst, int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     const int x = tid >> 4, pc = tid & 15;
@@ -418,7 +415,7 @@ __device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, con
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             if (RES && m + 3 < MT) xr[m + 3] = *(const uint4*)(xres + celloff + (m + 3) * 16 * HALO_STRIDE);
-            f32x4 o0 = acc[m][0] + b[0], o1 = acc[m][1] + b[1];
+            f32x4 o0 = acc[m][0], o1 = acc[m][1];
             if (RES) {
                 swap16(xr[m].x, xr[m].z);
                 swap16(xr[m].y, xr[m].w);
@@ -455,10 +452,10 @@ __device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, con
 }
 
 template <bool RES, bool KEEP>
-__device__ __forceinline__ void solo_epilogue(char* img, const char* xres, const f32x4 (&acc)[MT][2], const f32x4 (&b)[2],
+__device__ __forceinline__ void solo_epilogue(char* img, const char* xres, const f32x4 (&acc)[MT][2],
                                               bool relu, const char* mask, char* dst, int tid) {
-    if (mask) solo_epilogue_t<true, RES, KEEP>(img, xres, acc, b, relu, mask, dst, tid);
-    else solo_epilogue_t<false, RES, KEEP>(img, xres, acc, b, relu, mask, dst, tid);
+    if (mask) solo_epilogue_t<true, RES, KEEP>(img, xres, acc, relu, mask, dst, tid);
+    else solo_epilogue_t<false, RES, KEEP>(img, xres, acc, relu, mask, dst, tid);
 }
 
 // RANGE false: one tile per workgroup, entry blockIdx.x of the list in XCD order.  RANGE true: the
@@ -551,7 +548,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
         int s = 0;
         if (pre2 || pre1) {
 #pragma unroll
-            for (int m = 0; m < MT; m++) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int m = 0; m < MT; m++) { acc[m][0] = b_pre[0]; acc[m][1] = b_pre[1]; }      // (zeros without a bias)
             const int nsteps_pre = pre2 ? 8 : 4;
 #pragma unroll 1
             for (int c = 0; c < (pre2 ? 2 : 1); c++) {
@@ -560,28 +557,28 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
                     halo_stage(img2, arena + (int64_t)t.src1 * slot_b, 256, tid, false);
                     __syncthreads();
                 }
-                conv_kloop<1, false>(halo, xaddr2, wbase, wstep_pre, nsteps_pre, s, wr, acc, false);
+                conv_kloop<1, false>(halo, xaddr2, wbase, wstep_pre, nsteps_pre, s, wr, acc, b_pre, false);
             }
             wbase = (const char*)p.w_first + w33;
             load_wring(wr, wbase, wstep);
-            solo_epilogue<false, true>(halo, nullptr, acc, b_pre, pre2 && relu, t.pre_mask >= 0 ? arena + (int64_t)t.pre_mask * slot_b : nullptr,
+            solo_epilogue<false, true>(halo, nullptr, acc, pre2 && relu, t.pre_mask >= 0 ? arena + (int64_t)t.pre_mask * slot_b : nullptr,
                                        arena + (int64_t)t.res * slot_b, tid);
             s = 0;
         }
         STAMP(2);
-        conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+        conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, b_first, false);
         STAMP(3);
         wbase = (const char*)p.w_second + w33;
         load_wring(wr, wbase, wstep);
         // (every wave is past the 1x1 pass's reads of the second image: the barrier of that pass's epilogue)
-        solo_epilogue<false, true>(img2, nullptr, acc, b_first, relu, t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
+        solo_epilogue<false, true>(img2, nullptr, acc, relu, t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
         s = 0;
         STAMP(4);
-        conv_kloop<9, true>(halo, xaddr2, wbase, wstep, 36, s, wr, acc, false);
+        conv_kloop<9, true>(halo, xaddr2, wbase, wstep, 36, s, wr, acc, b_second, false);
         STAMP(5);
         // the result goes where the input is: each wave reads its own cells of it first, nobody else reads it
-        if (t.res >= 0) solo_epilogue<true, false>(halo, halo, acc, b_second, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
-        else solo_epilogue<false, false>(halo, nullptr, acc, b_second, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
+        if (t.res >= 0) solo_epilogue<true, false>(halo, halo, acc, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
+        else solo_epilogue<false, false>(halo, nullptr, acc, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
         STAMP(6);
 #undef STAMP
         return;
@@ -616,6 +613,8 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
     }
     bf16x8 wr[4][2];
     load_wring(wr, wbase, wstep_pre);
+    f32x4 bfirst[2];
+    lane_bias(bfirst, has_bias ? p.bias_first + (int64_t)t.wgroup * 128 : nullptr, wave, lq);
     halo_zero_border(halo, tid);
     f32x4 acc[MT][2];
     int xaddr[MT];
@@ -627,9 +626,12 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
     STAMP(1);
     int s = 0;
     if (pre2 || pre1) {   // x = [relu](pre(sources) + bias_pre) * (pre_mask > 0), kept in slot `res`
-        // (cleared registers here, not the zero-first form: with it the register allocator spills)
+        // (registers set to the bias - zeros without one - here, not the first-K-step form: with it the
+        // register allocator spills)
+        f32x4 bp[2];
+        lane_bias(bp, (pre2 && has_bias) ? p.bias_pre + (int64_t)t.wgroup * 128 : nullptr, wave, lq);
 #pragma unroll
-        for (int m = 0; m < MT; m++) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int m = 0; m < MT; m++) { acc[m][0] = bp[0]; acc[m][1] = bp[1]; }
         const int nsteps_pre = pre2 ? 8 : 4;
 #pragma unroll 1
         for (int c = 0; c < (pre2 ? 2 : 1); c++) {
@@ -638,31 +640,33 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
                 halo_stage(halo, arena + (int64_t)t.src1 * slot_b, 256, tid, false);
                 __syncthreads();
             }
-            conv_kloop<1, false>(halo, xaddr, wbase, wstep_pre, nsteps_pre, s, wr, acc, false);
+            conv_kloop<1, false>(halo, xaddr, wbase, wstep_pre, nsteps_pre, s, wr, acc, bp, false);
         }
         wbase = (const char*)p.w_first + w33;
         load_wring(wr, wbase, wstep);
-        acc_to_image(halo, acc, (pre2 && has_bias) ? p.bias_pre + (int64_t)t.wgroup * 128 : nullptr, pre2 && relu,
+        acc_to_image(halo, acc, pre2 && relu,
                      t.pre_mask >= 0 ? arena + (int64_t)t.pre_mask * slot_b : nullptr,
                      arena + (int64_t)t.res * slot_b, tid);
         s = 0;
     }
     STAMP(2);
-    conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+    conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, bfirst, false);
     STAMP(3);
 
-    // intermediate map -> the image the second convolution reads; its weight stream starts now and
-    // lands under the epilogue
+    // intermediate map -> the image the second convolution reads; its weight stream and its bias start
+    // now and land under the epilogue
     wbase = (const char*)p.w_second + w33;
     load_wring(wr, wbase, wstep);
-    acc_to_image(halo, acc, has_bias ? p.bias_first + (int64_t)t.wgroup * 128 : nullptr, relu,
+    f32x4 bsecond[2];
+    lane_bias(bsecond, has_bias ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr, wave, lq);
+    acc_to_image(halo, acc, relu,
                  t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
     s = 0;
     STAMP(4);
-    conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, false);
+    conv_kloop<9, true>(halo, xaddr, wbase, wstep, 36, s, wr, acc, bsecond, false);
     STAMP(5);
 
-    conv_epilogue(halo, acc, has_bias ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr, relu,
+    conv_epilogue(halo, acc, relu,
                   t.res >= 0 ? arena + (int64_t)t.res * slot_b : nullptr,
                   t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, 128, tid);
     STAMP(6);
