@@ -23,6 +23,7 @@
 #include "plan.h"
 #include "prof.h"
 #include <mutex>
+#include <type_traits>
 #include <string>
 
 #define XH_STRIDE 160                        // 64 channels + 32 bytes
@@ -120,37 +121,65 @@ __global__ __launch_bounds__(256, 2) void wgrad_tiles_kernel(vqa_wgrad_params p)
     const int doff = (prow * 16 + pcol) * DY_STRIDE + (4 * pp) * 2;               // + 32*ot, + kk, + r
 
     // the MFMA phase over the staged node: 7 k-steps of two image rows
-    auto mfma_phase = [&]() {
-#pragma unroll 1
-        for (int kk = 0; kk < 7; kk++) {
-            const char* xb = xh + xoff + kk * 32 * XH_STRIDE;
-            const char* db = dyt + doff + kk * 32 * DY_STRIDE;
-            bf16x8 bf[4];
+    // (the k-step's two base addresses are made opaque: every read is then that register plus a constant that fits
+    // the instruction's offset field; left to itself the compiler picks one base for the whole loop and spends a
+    // vector add per read on offsets that do not fit)
+    auto load_first = [&](bf16x8 (&bf)[4], bf16x8 (&ar)[2], int kk) {
+        int xo = xoff + kk * 32 * XH_STRIDE, dq = doff + kk * 32 * DY_STRIDE;
+        asm volatile("" : "+v"(xo), "+v"(dq));
+        const char* xb = xh + xo;
+        const char* db = dyt + dq;
 #pragma unroll
-            for (int o = 0; o < 4; o++)
-                bf[o] = frag_from_tr(lds_tr4(db + o * 32), lds_tr4(db + o * 32 + 8 * DY_STRIDE));
-            // taps run through a 3-deep ring of source fragments fetched two taps ahead, and the issue
-            // order is pinned (2 LDS reads : 4 MFMAs); otherwise every tap waits for its own reads
-            auto afrag = [&](int t) {
-                const int tapoff = (TAPS == 9) ? ((t / 3) * 16 + (t % 3)) : 17;
-                return frag_from_tr(lds_tr4(xb + tapoff * XH_STRIDE), lds_tr4(xb + (tapoff + 8) * XH_STRIDE));
-            };
-            bf16x8 ar[3];
-            ar[0] = afrag(0);
-            if (TAPS > 1) ar[1] = afrag(1);
+        for (int o = 0; o < 4; o++)
+            bf[o] = frag_from_tr(lds_tr4(db + o * 32), lds_tr4(db + o * 32 + 8 * DY_STRIDE));
 #pragma unroll
-            for (int t = 0; t < TAPS; t++) {
-                if (t + 2 < TAPS) ar[(t + 2) % 3] = afrag(t + 2);
-#pragma unroll
-                for (int o = 0; o < 4; o++) acc[t][o] = mma16(ar[t % 3], bf[o], acc[t][o]);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, TAPS > 1 ? 12 : 10, 0);
-#pragma unroll
-            for (int t = 0; t < TAPS; t++) {
-                if (t + 2 < TAPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
+        for (int t = 0; t < (TAPS > 1 ? 2 : 1); t++) {
+            const int tapoff = (TAPS == 9) ? ((t / 3) * 16 + (t % 3)) : 17;
+            ar[t] = frag_from_tr(lds_tr4(xb + tapoff * XH_STRIDE), lds_tr4(xb + (tapoff + 8) * XH_STRIDE));
         }
+    };
+    // One k-step: the taps run through a 3-deep ring of source fragments fetched two taps ahead, the issue order
+    // is pinned (2 LDS reads : 4 MFMAs; otherwise every tap waits for its own reads), and - NEXT - the first
+    // fragments of the following k-step (its four gradient fragments and first two source fragments: 12 reads, into
+    // registers the staging no longer needs) are asked for under this one's last taps: a k-step that begins by
+    // asking for them waits out an LDS round trip with the matrix pipe idle, seven times per node.
+    auto kstep = [&](const bf16x8 (&bf)[4], const bf16x8 (&a01)[2], int kk, auto next_tag, bf16x8 (&bfn)[4], bf16x8 (&an)[2]) {
+        constexpr bool NEXT = decltype(next_tag)::value;
+        constexpr int PF = TAPS > 4 ? TAPS - 4 : 0;            // the tap in front of which the next k-step's reads go
+        int xo = xoff + kk * 32 * XH_STRIDE;
+        asm volatile("" : "+v"(xo));
+        const char* xb = xh + xo;
+        auto afrag = [&](int t) {
+            const int tapoff = (TAPS == 9) ? ((t / 3) * 16 + (t % 3)) : 17;
+            return frag_from_tr(lds_tr4(xb + tapoff * XH_STRIDE), lds_tr4(xb + (tapoff + 8) * XH_STRIDE));
+        };
+        bf16x8 ar[3];
+        ar[0] = a01[0];
+        if (TAPS > 1) ar[1] = a01[1];
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) {
+            if (NEXT && t == PF) load_first(bfn, an, kk + 1);
+            if (t + 2 < TAPS) ar[(t + 2) % 3] = afrag(t + 2);
+#pragma unroll
+            for (int o = 0; o < 4; o++) acc[t][o] = mma16(ar[t % 3], bf[o], acc[t][o]);
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) {
+            if (NEXT && t == PF) __builtin_amdgcn_sched_group_barrier(0x100, TAPS > 1 ? 12 : 10, 0);
+            if (t + 2 < TAPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+    };
+    auto mfma_phase = [&]() {
+        bf16x8 bfa[4], bfb[4], aa[2], ab[2];
+        load_first(bfa, aa, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TAPS > 1 ? 12 : 10, 0);
+#pragma unroll 1
+        for (int kk = 0; kk < 6; kk += 2) {
+            kstep(bfa, aa, kk, std::true_type{}, bfb, ab);
+            kstep(bfb, ab, kk + 1, std::true_type{}, bfa, aa);
+        }
+        kstep(bfa, aa, 6, std::false_type{}, bfb, ab);
     };
 
     if constexpr (TAPS == 1) {
