@@ -180,6 +180,19 @@ typedef struct {
 
 int vqa_conv_tiles(const vqa_conv_params* p, int32_t taps /* 9 or 1 */, void* stream);
 
+/* The stem's first convolution straight from the reference's input layout (Module_Model.py:59-60,239 on
+ * the fp32 NCHW batch of Train_model.py:311): x fp32 [N][Cin][14][14], 3x3, Cin -> 128 channels, bias,
+ * [ReLU]; sample n goes to slot dst_slot_first + n of dst (bf16 [slot][196][dst_pix_stride]).  The layout
+ * change rides along inside the kernel (no vqa_nchw_to_nhwc pass); when x_nhwc is non-null the bf16
+ * channels-last copy [N][196][Cin] that the weight-gradient pass reads is written as well.  w: the
+ * convolution's weights packed by vqa_pack_conv_weight (one group, 128 outputs).  Cin % 128 == 0.
+ * Same bits as vqa_nchw_to_nhwc followed by vqa_conv_tiles. */
+int vqa_stem_nchw(const float* x, void* x_nhwc, void* dst, const void* w, const float* bias,
+                  int64_t dst_slot_stride, int32_t dst_slot_first, int32_t dst_pix_stride, int32_t N,
+                  int32_t Cin, int32_t flags /* bit 0: ReLU; bits 1-4 switch parts of the kernel off
+                  for timing (scripts/bench_stem.py) and give wrong results: leave them zero */,
+                  void* stream);
+
 /* Fused module body for module width 128: every convolution of one tree node in one workgroup
  * (Layers.py:33-36 / Module_Model.py:38-40,47-50 forward; their input gradients backward).  All
  * maps are slots of one arena, 256-byte pixels.

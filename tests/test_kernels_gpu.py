@@ -642,3 +642,34 @@ def test_wgrad1x1_wide_output_bias_rows():
     close(db2.cpu()[0], rb, 5e-3)
     close(db2.cpu(), db.cpu(), 1e-5)
     close(out.cpu(), rw, 5e-3)
+
+
+@pytest.mark.parametrize('Cin,S,with_copy', [(1024, 5, True), (128, 3, True), (256, 2, False)])
+def test_stem_from_nchw_equals_layout_pass_plus_convolution(Cin, S, with_copy):
+    """vqa_stem_nchw (the layout change inside the convolution kernel) against vqa_nchw_to_nhwc followed by
+    vqa_conv_tiles: the same bits in the output map and in the bf16 channels-last copy, and fp32 torch to the
+    kernels' usual tolerance."""
+    from vqa_amd import ops
+    C = 128
+    x = torch.relu(rnd((S, Cin, 14, 14), 31))
+    w = bf(rnd((1, C, Cin, 3, 3), 32, 0.02))
+    b = rnd((1, C), 33, 0.1)
+    xd = x.to(dev())
+    wp = ops.pack_conv_weight(w.to(dev()), 1, C, Cin, 9, 0, Cin * 9, 9)
+    # reference path: layout pass, then the grouped convolution over the channels-last copy
+    xn = torch.empty(S * HW * Cin, dtype=torch.bfloat16, device=dev())
+    ops.nchw_to_nhwc(xd, xn, S, Cin, Cin)
+    first = 2                                    # destination slots 2..: slots in front stay untouched
+    ref_dst = torch.zeros(first + S, HW, C, dtype=torch.bfloat16, device=dev())
+    tiles = tiles_tensor([[i, -1, first + i, -1, -1, -1, -1, 0] for i in range(S)])
+    ops.conv_tiles(xn, ref_dst, wp, tiles, S, taps=9, k_chunks=Cin // 128, n_out=C, src_slot_stride=HW * Cin,
+                   dst_slot_stride=HW * C, src_pix_stride=Cin, dst_pix_stride=C, w_group_stride=0, bias=b.to(dev()), relu=True)
+    dst = torch.zeros(first + S, HW, C, dtype=torch.bfloat16, device=dev())
+    copy = torch.full((S * HW * Cin,), 7.0, dtype=torch.bfloat16, device=dev()) if with_copy else None
+    for _ in range(2):
+        ops.stem_nchw(xd, copy, dst, wp, b.to(dev()), S, Cin, HW * C, first, C, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.view(torch.int16), ref_dst.view(torch.int16))
+    if with_copy:
+        assert torch.equal(copy.view(torch.int16), xn.view(torch.int16))
+    close(from_slots(dst[first:], C), F.relu(F.conv2d(bf(x), w[0], b[0], padding=1)))

@@ -100,6 +100,7 @@ SIGNATURES = {
     'vqa_plan_slot': (i32, [vp, i32, i32]),
     'vqa_conv_tiles': (i32, [C.POINTER(ConvParams), i32, vp]),
     'vqa_resblock_tiles': (i32, [C.POINTER(ResblockParams), vp]),
+    'vqa_stem_nchw': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     'vqa_devsched_build': (i32, [C.POINTER(DevschedParams), vp]),
     'vqa_conv_tiles_f32': (i32, [C.POINTER(ConvParams), i32, vp]),
     'vqa_wgrad_tiles_f32': (i32, [C.POINTER(WgradParams), i32, vp]),

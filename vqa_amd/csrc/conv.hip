@@ -284,6 +284,234 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The stem's first convolution straight from the reference's input: x fp32 [N][Cin][14][14]
+// (Train_model.py:311 hands the loader's NCHW batch to the executor; Module_Model.py:59-60,239 convolves it),
+// 3x3, Cin -> 128 channels, bias, ReLU, one sample per workgroup.  The layout change (fp32 planes -> bf16
+// channels-last) is not a pass of its own (1.2 GB of traffic per 1024 samples in front of an idle matrix
+// pipe): four PRODUCER waves turn chunk c + 1 of the sample into the halo image the K loop reads while four
+// CONSUMER waves run the K loop of vqa_conv_tiles over the image of chunk c.
+//   producer wave, 8 channels at a time: 16-byte loads along the planes (a chunk's 128 planes are 100 KB of
+//   contiguous memory), v_cvt_pk_bf16_f32, 8-byte stores into a private channel-major strip [8][128 pixels]
+//   in LDS; two transposing reads (ds_read_b64_tr_b16: 4 channels x 16 pixels each) hand every lane the 8
+//   channels of one pixel, i.e. one 16-byte cell of the image - and of the bf16 channels-last copy that the
+//   weight-gradient pass reads later, written from the same registers.  Strip rows are 320 bytes apart: the
+//   4 rows x 2 pixel blocks x 4 pieces of a 32-lane read land on 64 different banks.
+//   one workgroup barrier per chunk: the producers hand over image c & 1 and then fill the other one, which
+//   the consumers left before they came to that barrier.
+// LDS: two images + four strips = 162 304 bytes, one workgroup of 8 waves per CU.  Same fragments, same K
+// order, same rounding as vqa_nchw_to_nhwc + vqa_conv_tiles: the same bits.
+// ---------------------------------------------------------------------------------------------
+#define STRIP_STRIDE 320
+#define STRIP_BYTES (8 * STRIP_STRIDE)
+#define STEM_LDS (2 * HALO_BYTES + 4 * STRIP_BYTES)
+
+struct vqa_stem_params {
+    const float* x;          // fp32 [N][Cin][196]
+    void* x_nhwc;            // bf16 [N][196][Cin] or null
+    void* dst;               // bf16 base of destination slots
+    const void* w;           // packed weights of the convolution (one group)
+    const float* bias;       // fp32 [128] or null
+    int64_t dst_slot_stride; // elements
+    int32_t dst_slot_first;  // sample n goes to slot dst_slot_first + n
+    int32_t dst_pix_stride;
+    int32_t N, Cin;          // Cin % 128 == 0
+    int32_t relu;            // bit 0: ReLU; bits 1-4: diagnostics (producers idle / load only / do not load / read eight samples)
+};
+
+__global__ __launch_bounds__(512, 1) void stem_nchw_kernel(vqa_stem_params p) {
+    extern __shared__ __attribute__((aligned(16))) char halo[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x;
+    const int k_chunks = p.Cin >> 7;
+    char* const img2 = halo + HALO_BYTES;
+    // borders of both images, by everybody
+    for (int idx = tid; idx < 68 * 16; idx += 512) {
+        const int j = idx >> 4;
+        const int pos = j < 16 ? j : (j < 44 ? (((j - 16) >> 1) + 1) * 16 + ((j & 1) ? 15 : 0) : 240 + (j - 44));
+        *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(img2 + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+    }
+    if (wave >= 4) {
+        // ---------------- producers ----------------
+        const int pw = wave - 4;
+        char* strip = halo + 2 * HALO_BYTES + pw * STRIP_BYTES;
+        typedef float f32x4n __attribute__((ext_vector_type(4)));
+        const float* xs = p.x + (int64_t)((p.relu & 16) ? (n & 7) : n) * p.Cin * VQA_HW;     // (bit 16: diagnostics, eight samples for all)
+        // a lane's part of a group of 8 planes: pixels 0..127 of the planes are float4 f = lane + 64 i (i < 4:
+        // plane f >> 5, pixels 4 (f & 31)..), pixels 128..195 float4 f = lane + 64 i < 136 (plane f / 17)
+        int offa[4], offb[3], stra[4], strb[3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int f = lane + 64 * i;
+            offa[i] = (f >> 5) * VQA_HW + (f & 31) * 4;
+            stra[i] = (f >> 5) * STRIP_STRIDE + (f & 31) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int f = min(lane + 64 * i, 135), r = f / 17, k = f - r * 17;
+            offb[i] = r * VQA_HW + 128 + 4 * k;
+            strb[i] = r * STRIP_STRIDE + k * 8;
+        }
+        const bool lastb = lane + 128 < 136;
+        // transposing reads: lane 4 q + pp of a 16-lane group reads pixels 4 pp..4 pp + 3 of strip row q (and of row
+        // 4 + q); group g of pass it covers pixels 16 (4 it + g)..+15 of the strip
+        const int l15 = lane & 15, grp = lane >> 4;
+        const int troff = (l15 >> 2) * STRIP_STRIDE + (lane & 3) * 8 + grp * 32;
+        // image cell and channels-last offset of this lane's pixel in each of the four passes
+        int cell[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int px = (k >> 1) * 128 + (k & 1) * 64 + grp * 16 + l15;
+            ok[k] = px < VQA_HW;
+            const int pc = ok[k] ? px : 0, y = pc / 14, x = pc - y * 14;
+            cell[k] = ((y + 1) * 16 + x + 1) * HALO_STRIDE;
+        }
+        bf16_t* xn = p.x_nhwc ? (bf16_t*)p.x_nhwc + (int64_t)n * VQA_HW * p.Cin : nullptr;
+        // Group gq of chunk c: 8 of the wave's 32 planes.  One group is in flight while the one before it is
+        // processed: 7 to 14 loads per wave.  (With a half chunk - 28 loads a wave, 900 cache lines a CU - in flight
+        // the consumers' weight fragments, which come from L2 through the same L1, arrived late: the K loops of a
+        // sample took a third longer.)
+        f32x4n ra[7], rb[7];
+        const bool diag_noload = (p.relu & 8) != 0;
+        auto ask = [&](f32x4n (&r)[7], int c, int gq) {
+            if (diag_noload) return;
+            const float* g = xs + (int64_t)(c * 128 + pw * 32 + gq * 8) * VQA_HW;
+#pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = __builtin_nontemporal_load((const f32x4n*)(g + offa[i]));
+#pragma unroll
+            for (int i = 0; i < 3; i++) r[4 + i] = __builtin_nontemporal_load((const f32x4n*)(g + offb[i]));
+        };
+        auto put = [&](const f32x4n (&r)[7], int c, int gq) {
+            char* img = (c & 1) ? img2 : halo;
+            constexpr int gi = 0;
+            {
+                const int chl = pw * 32 + gq * 8;                 // first channel of the group within the chunk
+#pragma unroll
+                for (int part = 0; part < 2; part++) {
+                    if (part == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const f32x4n v = r[7 * gi + i];
+                            *(uint2*)(strip + stra[i]) = make_uint2(cvt_pk_bf16((f32x2){v[0], v[1]}), cvt_pk_bf16((f32x2){v[2], v[3]}));
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const f32x4n v = r[7 * gi + 4 + i];
+                            if (i < 2 || lastb)
+                                *(uint2*)(strip + strb[i]) = make_uint2(cvt_pk_bf16((f32x2){v[0], v[1]}), cvt_pk_bf16((f32x2){v[2], v[3]}));
+                        }
+                    }
+                    // (a lane reads what other lanes stored: nothing may move across these two lines; the LDS itself
+                    // runs a wave's instructions in order)
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int it = 0; it < 2; it++) {
+                        const s16x4 lo = lds_tr4(strip + troff + it * 128);
+                        const s16x4 hi = lds_tr4(strip + troff + it * 128 + 4 * STRIP_STRIDE);
+                        const uint4 v = __builtin_bit_cast(uint4, frag_from_tr(lo, hi));
+                        const int k = part * 2 + it;
+                        if (ok[k]) *(uint4*)(img + cell[k] + chl * 2) = v;
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+        };
+        const bool diag_idle = (p.relu & 2) != 0, diag_noput = (p.relu & 4) != 0;
+        if (!diag_idle) ask(ra, 0, 0);
+#pragma unroll 1
+        for (int c = 0; c < k_chunks; c++) {
+            if (!diag_idle) {
+            ask(rb, c, 1);
+            if (!diag_noput) put(ra, c, 0);
+            ask(ra, c, 2);
+            if (!diag_noput) put(rb, c, 1);
+            ask(rb, c, 3);
+            if (!diag_noput) put(ra, c, 2);
+            if (c + 1 < k_chunks) ask(ra, c + 1, 0);
+            if (!diag_noput) put(rb, c, 3);
+            if (diag_noput) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) asm volatile("" :: "v"(ra[i]), "v"(rb[i]));
+            }
+            }
+            lds_barrier();          // image c & 1 is the consumers'; they are out of the other one
+            if (xn) {
+                // the finished image (the consumers only read it) leaves as the bf16 channels-last copy in whole
+                // 256-byte rows: thread = (image column, 16-byte piece), 14 image rows
+                const int ptid = tid - 256, cx = ptid >> 4, pcs = ptid & 15;
+                if (cx < 14) {
+                    const char* im = ((c & 1) ? img2 : halo) + (16 + cx + 1) * HALO_STRIDE + pcs * 16;
+                    bf16_t* o = xn + (int64_t)cx * p.Cin + c * 128 + pcs * 8;
+#pragma unroll
+                    for (int y = 0; y < 14; y++)
+                        *(uint4*)(o + (int64_t)y * 14 * p.Cin) = *(const uint4*)(im + y * 16 * HALO_STRIDE);
+                }
+            }
+        }
+        // (the consumers' epilogue has four workgroup barriers)
+        lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
+        return;
+    }
+    // ---------------- consumers: the K loop and epilogue of conv_tiles_kernel<9>, images alternating ----------------
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t wstep = 8 * 1024;
+    const char* wbase = (const char*)p.w + (int64_t)(wave * 2) * 1024 + lane * 16;
+    const int nsteps = k_chunks * 36;
+    bf16x8 wr[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        wr[i][0] = *(const bf16x8*)(wbase + i * wstep);
+        wr[i][1] = *(const bf16x8*)(wbase + i * wstep + 1024);
+    }
+    f32x4 binit[2];
+    lane_bias(binit, p.bias, wave, lq);
+    int xaddr[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
+    f32x4 acc[MT][2];
+    int s = 0;
+    lds_barrier();
+    conv_kloop<9, true>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, binit, false);
+#pragma unroll 1
+    for (int c = 1; c < k_chunks; c++) {
+        lds_barrier();
+        // (the image's base goes into the lane's address register, made opaque: every read of the K loop is then
+        // that register plus a constant that fits the instruction's offset field)
+        int lb = l15 * HALO_STRIDE + lq * 16 + (c & 1) * HALO_BYTES;
+        asm volatile("" : "+v"(lb));
+        int xa[MT];
+#pragma unroll
+        for (int m = 0; m < MT; m++) xa[m] = m * 16 * HALO_STRIDE + lb;
+        conv_kloop<9, false>(halo, xa, wbase, wstep, nsteps, s, wr, acc, binit, false);
+    }
+    char* dptr = (char*)p.dst + (int64_t)(p.dst_slot_first + n) * p.dst_slot_stride * 2;
+    conv_epilogue(halo, acc, (p.relu & 1) != 0, nullptr, nullptr, dptr, p.dst_pix_stride, tid);
+}
+
+extern "C" int vqa_stem_nchw(const float* x, void* x_nhwc, void* dst, const void* w, const float* bias,
+                             int64_t dst_slot_stride, int32_t dst_slot_first, int32_t dst_pix_stride, int32_t N,
+                             int32_t Cin, int32_t flags, void* stream) {
+    if (!x || !dst || !w || N < 0 || Cin <= 0 || Cin % 128 != 0 || dst_pix_stride < 128 || dst_pix_stride % 8 != 0 ||
+        dst_slot_stride < (int64_t)VQA_HW * dst_pix_stride || dst_slot_first < 0) {
+        vqa_set_error("vqa_stem_nchw: bad argument");
+        return VQA_EINVAL;
+    }
+    if (N == 0) return VQA_OK;
+    if (!vqa_allow_lds((const void*)stem_nchw_kernel, STEM_LDS, "vqa_stem_nchw")) return VQA_ELAUNCH;
+    vqa_stem_params p;
+    p.x = x; p.x_nhwc = x_nhwc; p.dst = dst; p.w = w; p.bias = bias;
+    p.dst_slot_stride = dst_slot_stride; p.dst_slot_first = dst_slot_first; p.dst_pix_stride = dst_pix_stride;
+    p.N = N; p.Cin = Cin; p.relu = flags;
+    VqaProfScope prof(VQA_K_CONV9, 2.0 * VQA_HW * 9.0 * Cin * 128.0 * N, (double)N * VQA_HW * (4.0 * Cin + 2.0 * 128), (hipStream_t)stream);
+    hipLaunchKernelGGL(stem_nchw_kernel, dim3(N), dim3(512), STEM_LDS, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { vqa_set_error(std::string("vqa_stem_nchw: ") + hipGetErrorString(e)); return VQA_ELAUNCH; }
+    return VQA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused module body (module width 128 only): every convolution of one tree node in one workgroup.
 //   forward :  [P = relu(proj([x0; x1]) + bp)]   H = relu(conv1(x) + b1);   Y = relu(x + conv2(H) + b2)
 //              (Layers.py:33-36, Module_Model.py:38-40,47-50; x = P for a binary node)

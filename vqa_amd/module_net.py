@@ -185,6 +185,9 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
         # backward in two (vqa_head_forward / vqa_head_backward) instead of GEMM + bias and cast + column sum +
         # two GEMMs + column sum; False selects those (same operands, sums in another order)
         self.fuse_head = True
+        # fp32 NCHW features go into the stem's first convolution as they are (vqa_stem_nchw: the layout change
+        # inside the kernel, module width 128); False selects the layout pass + vqa_conv_tiles (same bits)
+        self.fuse_stem_layout = os.environ.get('VQA_FUSE_STEM', '1') != '0'
         # run nodes that have slack in later tree levels so that launches fill whole rounds of the device
         # (training calls only: in a forward-only call the device waits for the tile lists, and the
         # list scheduling costs the host more than the evener launches give back - 11 % of the call
@@ -479,6 +482,11 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
                                tiles_offset=8 * lo, **geo)
             if xs is None:
                 conv0(0, M)
+            elif self.fuse_stem_layout and c == 128 and cpad == d['cin'] and cpad % 128 == 0:
+                # the layout change happens inside the convolution kernel; the bf16 channels-last copy is
+                # written only when a backward pass will read it (the first convolution's weight gradient)
+                ops.stem_nchw(xs, xn if need_grad else None, arena_full, pk['w_stem0'], pk['b_stem0'], M, cpad,
+                              slot[0], M, slot[1], relu=True)
             else:
                 # fp32 NCHW -> bf16 channels-last is HBM-bound, the convolution behind it MFMA-bound:
                 # the batch goes through in pieces, the layout pass of piece k + 1 on a stream of its

@@ -272,6 +272,19 @@ def col_sum(x, out, rows, cols, ld):
                                        int(x.dtype == torch.bfloat16), _stream()))
 
 
+def stem_nchw(x, x_nhwc, dst, w_packed, bias, n, cin, dst_slot_stride, dst_slot_first, dst_pix_stride, relu=True):
+    """The stem's first convolution (3x3, cin -> 128) from the fp32 NCHW batch x [n][cin][14][14] into slots
+    dst_slot_first.. of dst; x_nhwc (or None) receives the bf16 channels-last copy [n][196][cin]"""
+    _need_cuda(x, dst, w_packed)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() >= n * cin * 196
+    assert dst.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and w_packed.numel() >= 9 * cin * 128
+    assert dst.numel() >= (dst_slot_first + n - 1) * dst_slot_stride + 196 * dst_pix_stride
+    assert x_nhwc is None or (x_nhwc.dtype == torch.bfloat16 and x_nhwc.numel() >= n * 196 * cin)
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= 128)
+    _lib.check(_lib.load().vqa_stem_nchw(_ptr(x), _ptr(x_nhwc), _ptr(dst), _ptr(w_packed), _ptr(bias), dst_slot_stride,
+                                         dst_slot_first, dst_pix_stride, n, cin, int(relu), _stream()))
+
+
 def head_forward(act, ld_act, w, ld_w, bias, logits, n, f, a):
     """logits fp32 [n][a] = act bf16 [n][ld_act] x w bf16 [a][ld_w]^T + bias: the classifier's last linear
     layer (Module_Model.py:92) in one launch"""
