@@ -129,7 +129,10 @@ enum {
     VQA_SEC_SLOTS_SCDZ, VQA_SEC_SLOTS_SCY, /* per sample: dZ slot of its scene node that runs; that node's output slot */
     VQA_SEC_SCENE_DPROJ_TILES, /* conv tiles, fused path only: dP(binary node) -> dZ of those of its inputs that
                                   are scene nodes (the other destination is -1), masks = their outputs */
-    VQA_SEC_COUNT
+VQA_SEC_WG_ITEMS_12, VQA_SEC_WG_SRC_12, VQA_SEC_WG_DY_12, /* both 3x3 weight gradients of the tree as ONE item list
+                                  (longest first; items of the second convolution carry group V + token and index the
+                                  second half of the two slot lists): one launch instead of two half-filled tails */
+        VQA_SEC_COUNT
 };
 int vqa_plan_section(const vqa_plan* plan, int32_t id, int32_t* offset, int32_t* count);
 /* arena slot ids (slot s is the map at arena + s * 196 * C elements): which = 0 F(sample) 1 S0(sample) 2 Y(node) 3 H(node)

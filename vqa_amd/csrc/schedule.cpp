@@ -433,6 +433,23 @@ void build_backward_part(vqa_plan* pl) {
     put(VQA_SEC_WG_PSRC0, psrc0, (int)psrc0.size());
     put(VQA_SEC_WG_PSRC1, psrc1, (int)psrc1.size());
     put(VQA_SEC_WG_PDY, pdy, (int)pdy.size());
+    // Both 3x3 weight gradients as one launch: a launch of 300-odd items x 4 workgroups is two and a half rounds of
+    // the device and ends on a round that is less than half full; one launch of twice the items ends on one such
+    // round instead of two.  Items of the second convolution: group V + token, slots in the second half of the lists.
+    {
+        std::vector<int32_t> items12(items), src12(src_c1), dy12(dy_c1);
+        const int32_t half = (int32_t)src_c1.size();
+        for (size_t k = 0; k < items.size(); k += 4) {
+            const int32_t it[4] = {items[k] + V, items[k + 1] + half, items[k + 2], 0};
+            items12.insert(items12.end(), it, it + 4);
+        }
+        src12.insert(src12.end(), src_c2.begin(), src_c2.end());
+        dy12.insert(dy12.end(), dy_c2.begin(), dy_c2.end());
+        by_count(items12);
+        put(VQA_SEC_WG_ITEMS_12, items12, (int)items12.size() / 4);
+        put(VQA_SEC_WG_SRC_12, src12, (int)src12.size());
+        put(VQA_SEC_WG_DY_12, dy12, (int)dy12.size());
+    }
 }
 
 }  // namespace
@@ -619,7 +636,7 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     pl->has_separate = !(flags & VQA_PLAN_SKIP_SEPARATE);
     pl->has_fused = !(flags & VQA_PLAN_SKIP_FUSED);
     // upper bound of the finished blob, so that a caller can size its buffers after the forward part
-    pl->blob_bound = (size_t)NV * 80 + (size_t)N * 64 + (size_t)nb * 32 + (size_t)V * 16 + 1024;
+    pl->blob_bound = (size_t)NV * 88 + (size_t)N * 64 + (size_t)nb * 32 + (size_t)V * 32 + 1024;
     pl->blob.reserve(pl->blob_bound);
     build_forward_part(pl);
     pl->fwd_words = (int)pl->blob.size();
@@ -658,7 +675,8 @@ extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
         const int cc = pl->C / 128, os = pl->C / 64;
         const int it = pl->sec_cnt[VQA_SEC_WG_ITEMS], pit = pl->sec_cnt[VQA_SEC_WG_PITEMS];
         auto rows = [&](int items) { return (int)(((int64_t)items * pl->C + 8191) / 8192); };
-        o->wgrad_partial_blocks = std::max(it * os * cc * 9 + rows(it), pit * os * 2 * cc + rows(pit));
+        // (the two 3x3 weight gradients of the tree run as one launch: twice the items)
+        o->wgrad_partial_blocks = std::max(2 * it * os * cc * 9 + rows(2 * it), pit * os * 2 * cc + rows(pit));
     }
     return VQA_OK;
 }

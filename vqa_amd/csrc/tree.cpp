@@ -204,16 +204,32 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     // partial blocks, and behind them one row of bias sums per item: both summed per token by
     // vqa_wgrad_reduce in item order, so every gradient comes out the same on every run
     w.partial = c->wgrad_partial;
-    w.bias_block = w.num_items * (pl->C / 64) * cc * 9;
-    const float* bias_rows = w.partial + (int64_t)w.bias_block * 8192;
-    w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C1];
-    w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C1];
-    if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
-    if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv1, w33, bias_rows, c->gb_conv1, stream))) return rc;
-    w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C2];
-    w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C2];
-    if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
-    if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv2, w33, bias_rows, c->gb_conv2, stream))) return rc;
+    const float* bias_rows;
+    if (c->g_conv2 == c->g_conv1 + (int64_t)c->V * w33 && c->gb_conv2 == c->gb_conv1 + (int64_t)c->V * pl->C &&
+        pl->sec_cnt[VQA_SEC_WG_ITEMS_12] == 2 * w.num_items) {
+        // the caller's two gradient arrays are one [2 V][...] array: both convolutions' weight gradients as one launch
+        // over the merged item list (groups V.. are the second convolution's), and one reduction
+        w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_ITEMS_12]);
+        w.num_items = pl->sec_cnt[VQA_SEC_WG_ITEMS_12];
+        w.total_nodes = 2 * pl->num_exec;
+        w.bias_block = w.num_items * (pl->C / 64) * cc * 9;
+        bias_rows = w.partial + (int64_t)w.bias_block * 8192;
+        w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_12];
+        w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_12];
+        if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
+        if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, 2 * c->V, pl->C, cc, 9, c->g_conv1, w33, bias_rows, c->gb_conv1, stream))) return rc;
+    } else {
+        w.bias_block = w.num_items * (pl->C / 64) * cc * 9;
+        bias_rows = w.partial + (int64_t)w.bias_block * 8192;
+        w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C1];
+        w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C1];
+        if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
+        if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv1, w33, bias_rows, c->gb_conv1, stream))) return rc;
+        w.src_slots = c->blob + pl->sec_off[VQA_SEC_WG_SRC_C2];
+        w.dy_slots = c->blob + pl->sec_off[VQA_SEC_WG_DY_C2];
+        if ((rc = vqa_wgrad_tiles(&w, 9, stream))) return rc;
+        if ((rc = vqa_wgrad_reduce(w.partial, w.items, w.num_items, c->V, pl->C, cc, 9, c->g_conv2, w33, bias_rows, c->gb_conv2, stream))) return rc;
+    }
     if (pl->sec_cnt[VQA_SEC_WG_PITEMS] > 0) {
         w.items = (const vqa_wgrad_item*)(c->blob + pl->sec_off[VQA_SEC_WG_PITEMS]);
         w.num_items = pl->sec_cnt[VQA_SEC_WG_PITEMS];

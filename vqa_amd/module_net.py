@@ -904,12 +904,14 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
                    mask=arena)
 
         # ---- module trees: input gradients by level, scene fan-in, all weight gradients
-        gw1 = torch.empty(nv, c, c, 3, 3, **f32)
-        gw2 = torch.empty(nv, c, c, 3, 3, **f32)
+        # (the two 3x3 gradient arrays are the halves of one array: vqa_tree_backward then runs both weight
+        # gradients as one launch over a merged item list)
+        gw12, gb12 = torch.empty(2 * nv, c, c, 3, 3, **f32), torch.empty(2 * nv, c, **f32)
+        gw1, gw2 = gw12[:nv], gw12[nv:]
         gwp = torch.empty(nv, c, 2 * c, 1, 1, **f32)
         # (all six arrays are written whole by the reductions, rows of unused tokens as zeros)
-        acc = {'g_conv1': gw1, 'g_conv2': gw2, 'g_proj': gwp, 'gb_conv1': torch.empty(nv, c, **f32),
-               'gb_conv2': torch.empty(nv, c, **f32), 'gb_proj': torch.empty(nv, c, **f32)}
+        acc = {'g_conv1': gw1, 'g_conv2': gw2, 'g_proj': gwp, 'gb_conv1': gb12[:nv],
+               'gb_conv2': gb12[nv:], 'gb_proj': torch.empty(nv, c, **f32)}
         tctx = self._tree_ctx(st, pk, acc)
         tctx.wgrad_partial = part.data_ptr()
         self._mark('cls_bwd')
