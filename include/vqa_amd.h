@@ -465,10 +465,11 @@ int vqa_head_backward(const float* dlogits, const void* act, int64_t ld_act, con
                       void* gin, int64_t ld_gin, float* dw, float* db_in, float* db, float* workspace,
                       int32_t N, int32_t F, int32_t A, void* stream);
 /* loss[0] = mean over n of (logsumexp(logits[n]) - logits[n][target[n]]) and its gradient
- * dlogits = (softmax(logits) - onehot(target)) / N, fp32 [N][A], in one launch; targets int64 in
- * [0, A) (a row whose target is out of range adds nothing to either) */
-int vqa_xent(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t N, int32_t A,
-             void* stream);
+ * dlogits = (softmax(logits) - onehot(target)) / N, fp32 [N][A], in two launches (rows, then the sum of
+ * per-workgroup partial losses in a fixed order); targets int64 in [0, A) (a row whose target is out of
+ * range adds nothing to either); workspace: 128 floats */
+int vqa_xent(const float* logits, const int64_t* target, float* loss, float* dlogits, float* workspace, int32_t N,
+             int32_t A, void* stream);
 
 /* dst slot <- (sum of listed source slots) * (mask slot > 0): scene-node gradient fan-in
  * (feats[i:i+1] is read by every scene node of sample i, Module_Model.py:214) */

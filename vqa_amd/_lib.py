@@ -125,7 +125,7 @@ SIGNATURES = {
     'vqa_head_forward': (i32, [vp, i64, vp, i64, vp, vp, i32, i32, i32, vp]),
     'vqa_head_backward_workspace': (i64, [i32, i32, i32]),
     'vqa_head_backward': (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]),
-    'vqa_xent': (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    'vqa_xent': (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
     'vqa_gather_rows': (i32, [vp, i64, i64, vp, i64, vp, i32]),
     'vqa_adam_tensors': (i32, [vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     'vqa_adam_fc1': (i32, [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -1,7 +1,7 @@
 // The classifier's last linear layer (F -> A answers, A <= 64) forward and backward, and the
 // cross-entropy loss behind it (gfx950).  33 MFLOP at the default sizes: what these passes cost is
 // launches, not arithmetic - as GEMM + bias, cast + column sum + two GEMMs + column sum, and torch's
-// softmax / nll_loss kernels they were sixteen launches per training step; here they are five.
+// softmax / nll_loss kernels they were sixteen launches per training step; here they are six.
 // Operands are rounded to bf16 where the MFMA path rounds them (activations, weights, the gradient of
 // the logits), products are summed in fp32 in a fixed order: every result is the same on every run.
 //
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void head_backward_reduce_kernel(const float* 
         const int o = idx / F, i = idx - o * F;
         if (o < A || o == AT) {
             float t = 0.f;
-            for (int s = 0; s < S; s++) t += part[(int64_t)s * total + idx];
+#pragma unroll 8
+            for (int s = 0; s < S; s++) t += part[(int64_t)s * total + idx];      // (eight loads in flight, added in slice order)
             if (o == AT) db_in[i] = t;
             else dw[(int64_t)o * F + i] = t;
         }
@@ -213,43 +214,70 @@ extern "C" int vqa_head_backward(const float* dlogits, const void* act, int64_t 
 }
 
 // loss = mean_n( logsumexp(logits[n]) - logits[n][target[n]] ),  dlogits = (softmax - onehot) / N:
-// torch.nn.CrossEntropyLoss (mean reduction) forward and backward in one launch of one workgroup;
-// thread = rows tid, tid + 1024, ...; the rows' losses are added in a fixed order.
-__global__ __launch_bounds__(1024) void xent_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
-                                                    float* __restrict__ loss, float* __restrict__ dlogits, int N, int A) {
-    __shared__ float red[1024];
-    const int tid = threadIdx.x;
+// torch.nn.CrossEntropyLoss (mean reduction) forward and backward.  A row is spread over 32 lanes (coalesced
+// accesses, the row's maximum and sum by lane exchanges), a workgroup of 256 threads takes 8 rows at a time and a
+// contiguous range of rows in all; it leaves the sum of its rows' losses, added in row order, in `partial`, and
+// a one-workgroup launch adds the partial sums in workgroup order: the same bits on every run.  (As ONE
+// workgroup with a row per thread the pass took 68 us on the critical path of a step.)
+#define XENT_BLOCKS 128
+__global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                        float* __restrict__ partial, float* __restrict__ dlogits, int N, int A,
+                                                        int rows_per_block) {
+    __shared__ float rowloss[8];
+    const int tid = threadIdx.x, sub = tid >> 5, l = tid & 31;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
     const float inv_n = 1.f / (float)N;
-    float mine = 0.f;
-    for (int n = tid; n < N; n += 1024) {
-        const float* x = logits + (int64_t)n * A;
-        float m = x[0];
-        for (int o = 1; o < A; o++) m = fmaxf(m, x[o]);
+    float total = 0.f;                                   // (thread 0 only)
+    for (int base = r0; base < r1; base += 8) {
+        const int n = base + sub;
+        const bool live = n < r1;
+        const float* x = logits + (int64_t)(live ? n : r0) * A;
+        float m = -INFINITY;
+        for (int o = l; o < A; o += 32) m = fmaxf(m, x[o]);
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 32));
         float sum = 0.f;
-        for (int o = 0; o < A; o++) sum += expf(x[o] - m);
+        for (int o = l; o < A; o += 32) sum += expf(x[o] - m);
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 32);
         const float lse = m + logf(sum);
-        const int64_t t = target[n];
-        const bool valid = t >= 0 && t < A;          // (out of range: the row adds nothing, like an ignored index)
-        if (valid) mine += lse - x[t];
-        float* d = dlogits + (int64_t)n * A;
-        for (int o = 0; o < A; o++) d[o] = valid ? (expf(x[o] - lse) - (o == t ? 1.f : 0.f)) * inv_n : 0.f;
-    }
-    red[tid] = mine;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (tid < w) red[tid] += red[tid + w];
+        const int64_t t = target[live ? n : r0];
+        const bool valid = t >= 0 && t < A;              // (out of range: the row adds nothing, like an ignored index)
+        if (live) {
+            float* dl = dlogits + (int64_t)n * A;
+            for (int o = l; o < A; o += 32) dl[o] = valid ? (expf(x[o] - lse) - (o == t ? 1.f : 0.f)) * inv_n : 0.f;
+        }
+        if (l == 0) rowloss[sub] = (live && valid) ? lse - x[t] : 0.f;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) total += rowloss[k];
+        }
         __syncthreads();
     }
-    if (tid == 0) loss[0] = red[0] * inv_n;
+    if (tid == 0) partial[blockIdx.x] = total;
 }
 
-extern "C" int vqa_xent(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t N, int32_t A,
-                        void* stream) {
-    if (!logits || !target || !loss || !dlogits || N <= 0 || A <= 0) {
+__global__ __launch_bounds__(64) void xent_sum_kernel(const float* __restrict__ partial, float* __restrict__ loss, int blocks, int N) {
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int b = 0; b < blocks; b++) t += partial[b];
+        loss[0] = t / (float)N;
+    }
+}
+
+extern "C" int vqa_xent(const float* logits, const int64_t* target, float* loss, float* dlogits, float* workspace, int32_t N,
+                        int32_t A, void* stream) {
+    if (!logits || !target || !loss || !dlogits || !workspace || N <= 0 || A <= 0) {
         vqa_set_error("vqa_xent: bad argument");
         return VQA_EINVAL;
     }
-    hipLaunchKernelGGL(xent_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, target, loss, dlogits, N, A);
+    const int rows_per_block = ((N + XENT_BLOCKS - 1) / XENT_BLOCKS + 7) / 8 * 8;
+    const int blocks = (N + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(xent_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, target, workspace, dlogits, N, A,
+                       rows_per_block);
+    HEAD_CHECK_LAUNCH("vqa_xent");
+    hipLaunchKernelGGL(xent_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, loss, blocks, N);
     HEAD_CHECK_LAUNCH("vqa_xent");
     return VQA_OK;
 }

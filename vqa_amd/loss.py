@@ -1,4 +1,4 @@
-"""Cross-entropy for the executor's logits in one launch (torch.nn.CrossEntropyLoss of
+"""Cross-entropy for the executor's logits in two small launches (torch.nn.CrossEntropyLoss of
 Train_model.py:185,312 takes seven: log-softmax, gather, mean, and their gradients).
 
     loss_fn = vqa_amd.loss.CrossEntropyLoss()

@@ -310,12 +310,13 @@ def head_backward(dlogits, act, ld_act, w, ld_w, gin, ld_gin, dw, db_in, db, wor
 
 
 def xent(logits, target, loss, dlogits):
-    """Mean cross-entropy of fp32 logits [n][a] against int64 targets, and its gradient, in one launch"""
+    """Mean cross-entropy of fp32 logits [n][a] against int64 targets, and its gradient (two small launches)"""
     n, a = logits.shape
     assert logits.dtype == dlogits.dtype == loss.dtype == torch.float32 and target.dtype == torch.int64
     assert logits.is_contiguous() and dlogits.is_contiguous() and target.is_contiguous()
     assert target.numel() == n and dlogits.numel() == n * a and loss.numel() >= 1
-    _lib.check(_lib.load().vqa_xent(_ptr(logits), _ptr(target), _ptr(loss), _ptr(dlogits), n, a, _stream()))
+    ws = torch.empty(128, dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().vqa_xent(_ptr(logits), _ptr(target), _ptr(loss), _ptr(dlogits), _ptr(ws), n, a, _stream()))
 
 
 def slot_sum_mask(arena, blob, off_offsets, off_src, off_dst, off_mask, n_dst, slot_elems):
