@@ -57,6 +57,7 @@ typedef struct {
     int32_t num_exec_nodes; /* nodes that run: all the scene nodes of an image compute the same map, one does */
     int32_t blob_fwd_words; /* leading part of the blob that the forward pass reads */
     int32_t blob_words_bound; /* upper bound of blob_words once the plan is finished (VQA_PLAN_DEFER_BACKWARD) */
+    int32_t blob_lent;      /* 1: the blob is in the memory given to vqa_schedule_build_into */
 } vqa_plan_info;
 
 /* programs: host int64 [N][T].  arity: int8 [V] (0 scene, 1 unary, 2 binary), indexed by token id
@@ -91,6 +92,21 @@ int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int32_t T, con
                               int32_t V, int32_t null_id, int32_t start_id, int32_t scene_id, int32_t C,
                               int32_t wgrad_chunk, int32_t flags, const int32_t* image_of_sample,
                               int32_t num_images, vqa_plan** out);
+/* Either of the two above (image_of_sample NULL and num_images = N for the first), with the blob
+ * written straight into memory of the caller's: blob_store, of blob_store_words int32 words, e.g.
+ * pinned host memory that an asynchronous copy to the device can read without a staging copy.  The
+ * memory is used if it holds the finished blob's upper bound (88 words per node and 32 more per
+ * two-input node, of at most N * (T + 1) nodes, plus 64 N + 32 V + 1024), and then belongs to the
+ * plan until vqa_plan_free:
+ * vqa_plan_finish appends to it, vqa_plan_get_info reports blob_lent = 1 and the blob's words are
+ * blob_store[0 .. blob_words).  If it is NULL or too small the plan keeps the blob in memory of its
+ * own (blob_lent = 0, vqa_plan_blob / vqa_plan_blob_range copy it out).  No counterpart in the
+ * reference, whose helper (Module_Model.py:196-222) runs the modules as it parses. */
+int vqa_schedule_build_into(const int64_t* programs, int32_t N, int32_t T, const int8_t* arity,
+                            int32_t V, int32_t null_id, int32_t start_id, int32_t scene_id, int32_t C,
+                            int32_t wgrad_chunk, int32_t flags, const int32_t* image_of_sample,
+                            int32_t num_images, int32_t* blob_store, int64_t blob_store_words,
+                            vqa_plan** out);
 void vqa_plan_free(vqa_plan* plan);
 int vqa_plan_get_info(const vqa_plan* plan, vqa_plan_info* out);
 /* used_fns as ModuleNet.used_fns (Module_Model.py:227,231): float [N][T] of 0/1 */

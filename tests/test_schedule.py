@@ -236,3 +236,44 @@ def test_deferred_backward_part_gives_the_same_blob(vocab):
         part.blob_range_into(buf, nf, whole.info.blob_words - nf)
         np.testing.assert_array_equal(buf.numpy()[nf:], whole.blob()[nf:])
         assert (buf.numpy()[:nf] == 0).all()
+
+
+def test_blob_written_into_the_callers_memory(vocab):
+    """vqa_schedule_build_into: a store that holds the blob's upper bound receives the blob itself
+    (forward part, then what vqa_plan_finish appends), word for word what a plan with memory of its
+    own holds; a store that is too small is left alone.  Plans are pooled, so one that lent memory
+    must come back clean."""
+    import torch
+    from vqa_amd import _lib
+    prog = synth.synth_programs(77, 150, vocab)
+    n, t = prog.shape
+    flags = _lib.PLAN_SKIP_SEPARATE | _lib.PLAN_BALANCE | _lib.PLAN_DEFER_BACKWARD
+    own = Plan(prog, vocab, flags=flags)
+    words = Plan.blob_store_words(n, t, len(vocab['program_token_to_idx']))
+    assert words >= own.info.blob_words_bound
+    store = torch.full((words,), -7, dtype=torch.int32)
+    lent = Plan(prog, vocab, flags=flags, blob_store=store)
+    assert lent.info.blob_lent == 1 and own.info.blob_lent == 0
+    nf = lent.info.blob_words
+    np.testing.assert_array_equal(store[:nf].numpy(), own.blob())
+    assert (store[nf:] == -7).all()
+    own.finish(); lent.finish()
+    total = lent.info.blob_words
+    assert total == own.info.blob_words > nf
+    np.testing.assert_array_equal(store[:total].numpy(), own.blob())
+    np.testing.assert_array_equal(lent.blob(), own.blob())
+    assert (store[total:] == -7).all()
+    for name in _lib.SEC:
+        assert lent.section(name) == own.section(name)
+    del lent
+    small = torch.full((own.info.blob_words_bound - 1,), -7, dtype=torch.int32)
+    p = Plan(prog, vocab, flags=flags, blob_store=small)     # most likely the pooled object that lent
+    assert p.info.blob_lent == 0 and (small == -7).all()
+    p.finish()
+    np.testing.assert_array_equal(p.blob(), own.blob())
+    # samples that share images
+    img = np.arange(n) // 3
+    a = Plan(prog, vocab, flags=_lib.PLAN_SKIP_SEPARATE, image_index=img)
+    b = Plan(prog, vocab, flags=_lib.PLAN_SKIP_SEPARATE, image_index=img, blob_store=store)
+    assert b.info.blob_lent == 1
+    np.testing.assert_array_equal(store[:b.info.blob_words].numpy(), a.blob())

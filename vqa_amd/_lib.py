@@ -18,7 +18,7 @@ class PlanInfo(C.Structure):
                                    'num_binary', 'num_levels', 'slots_fwd', 'slots_total',
                                    'blob_words', 'wgrad_items', 'max_level_tiles',
                                    'wgrad_partial_blocks', 'num_images', 'num_exec_nodes',
-                                   'blob_fwd_words', 'blob_words_bound')]
+                                   'blob_fwd_words', 'blob_words_bound', 'blob_lent')]
 
 
 class ConvParams(C.Structure):
@@ -86,6 +86,8 @@ SIGNATURES = {
                                  C.POINTER(vp)]),
     'vqa_schedule_build_shared': (i32, [i64p, i32, i32, i8p, i32, i32, i32, i32, i32, i32, i32, i32p, i32,
                                         C.POINTER(vp)]),
+    'vqa_schedule_build_into': (i32, [i64p, i32, i32, i8p, i32, i32, i32, i32, i32, i32, i32, i32p, i32,
+                                      i32p, i64, C.POINTER(vp)]),
     'vqa_plan_free': (None, [vp]),
     'vqa_plan_get_info': (i32, [vp, C.POINTER(PlanInfo)]),
     'vqa_plan_used_fns': (i32, [vp, f32p]),

@@ -16,6 +16,52 @@ struct PlanLevel {
     int off_fused_fwd = 0, off_fused_bwd = 0;   // residual body as one tile (vqa_resblock_tiles)
 };
 
+// The tile lists: a growing int32 array with the parts of std::vector's interface that the scheduler
+// uses, in the plan's own memory or in memory that the caller lends (pinned memory, say, so that the
+// upload needs no staging copy).  resize() leaves new words unwritten.
+class PlanBlob {
+public:
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    bool lent() const { return lent_; }
+    int32_t* data() { return p_; }
+    const int32_t* data() const { return p_; }
+    int32_t* begin() { return p_; }
+    int32_t* end() { return p_ + n_; }
+    int32_t& operator[](size_t i) { return p_[i]; }
+    const int32_t& operator[](size_t i) const { return p_[i]; }
+    void clear() { n_ = 0; }
+    void reserve(size_t cap) {
+        if (cap <= cap_) return;
+        // lent memory that turns out too small is given up for memory of the plan's own
+        std::vector<int32_t> grown(cap);
+        for (size_t i = 0; i < n_; i++) grown[i] = p_[i];
+        own_.swap(grown);
+        p_ = own_.data(); cap_ = own_.size(); lent_ = false;
+    }
+    void resize(size_t n) {
+        if (n > cap_) reserve(n > 2 * cap_ ? n : 2 * cap_);
+        n_ = n;
+    }
+    void push_back(int32_t v) {
+        if (n_ == cap_) reserve(cap_ ? 2 * cap_ : 1024);
+        p_[n_++] = v;
+    }
+    template <class It>
+    void insert(const int32_t* at, It first, It last) {   // appends only: at == end()
+        (void)at;
+        for (; first != last; ++first) push_back((int32_t)*first);
+    }
+    void lend(int32_t* p, size_t cap) { p_ = p; cap_ = cap; n_ = 0; lent_ = true; }
+    void unlend() { p_ = own_.data(); cap_ = own_.size(); n_ = 0; lent_ = false; }
+
+private:
+    std::vector<int32_t> own_;
+    int32_t* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+    bool lent_ = false;
+};
+
 struct vqa_plan {
     int N = 0, T = 0, C = 0, V = 0;
     int M = 0;                        // images: N, or fewer when samples share images (forward only)
@@ -31,7 +77,8 @@ struct vqa_plan {
     int num_exec = 0;                 // nodes that run (all but the aliased scene nodes)
     std::vector<std::vector<int>> level_nodes;
     std::vector<PlanLevel> levels;
-    std::vector<int32_t> blob;
+    PlanBlob blob;
+    std::vector<int32_t> work;        // build scratch, kept for its capacity
     int num_scene = 0, num_unary = 0, num_binary = 0, num_levels = 0, max_level_tiles = 0;
     int slot_F = 0, slot_S0 = 0, slot_Ysc = 0, slot_Hsc = 0, slot_Y = 0, slot_H = 0, slot_P = 0, slots_fwd = 0;
     int slot_dHsc = 0;

@@ -55,7 +55,7 @@ void plan_release(vqa_plan* p) {
     p->bin_index.clear(); p->scene_index.clear(); p->token_counts.clear(); p->rep.clear(); p->first_scene.clear();
     p->num_exec = 0;
     for (auto& lv : p->level_nodes) lv.clear();
-    p->levels.clear(); p->blob.clear();
+    p->levels.clear(); p->blob.unlend();
     p->num_scene = p->num_unary = p->num_binary = p->num_levels = p->max_level_tiles = 0;
     p->slot_F = p->slot_S0 = p->slot_Ysc = p->slot_Hsc = p->slot_Y = p->slot_H = p->slot_P = p->slots_fwd = 0;
     p->slot_dHsc = p->slot_dZ = p->slot_dH = p->slot_dP = p->slot_dFp = p->slot_dF = p->slot_dS0 = p->slots_total = 0;
@@ -144,7 +144,7 @@ int parse_row(const int64_t* row, int T, const int8_t* arity, int V, int null_id
     }
 }
 
-inline void push_tile(std::vector<int32_t>& b, int s0, int s1, int d0, int d1, int res, int m0, int m1,
+inline void push_tile(PlanBlob& b, int s0, int s1, int d0, int d1, int res, int m0, int m1,
                       int wg) {
     const size_t at = b.size();
     b.resize(at + 8);            // capacity is reserved up front: no reallocation here
@@ -176,7 +176,7 @@ inline int in_slot(const vqa_plan* pl, int v) {   // slot the residual body of n
 // so that a caller can upload it and start the forward launches while the backward half is still
 // being written (VQA_PLAN_DEFER_BACKWARD, vqa_plan_finish).
 void build_forward_part(vqa_plan* pl) {
-    std::vector<int32_t>& b = pl->blob;
+    PlanBlob& b = pl->blob;
     const int N = pl->N, M = pl->M;
     pl->levels.assign(pl->num_levels, {});
     int max_tiles = 0;
@@ -208,13 +208,23 @@ void build_forward_part(vqa_plan* pl) {
             // the same passes as one fused tile per node (vqa_resblock_tile, 12 words):
             // [children -> P] -> H -> Y
             lv.off_fused_fwd = (int)b.size();
+            b.resize(b.size() + (size_t)12 * nodes.size());   // within the reserved capacity
+            int32_t* w = b.data() + lv.off_fused_fwd;
+            const PlanNode* N_ = pl->nodes.data();
+            const int sid = pl->scene_id;
             for (int v : nodes) {
-                const PlanNode& nd = pl->nodes[v];
-                const int in = in_slot(pl, v);
-                const bool bin = nd.child1 >= 0;
-                const int32_t w[12] = {bin ? y_slot(pl, nd.child0) : in, bin ? y_slot(pl, nd.child1) : -1,
-                                       y_slot(pl, v), h_slot(pl, v), in, -1, -1, nd.token, -1, -1, -1, -1};
-                b.insert(b.end(), w, w + 12);
+                const PlanNode& nd = N_[v];
+                const int c0 = nd.child0 < 0 ? 0 : nd.child0, c1 = nd.child1 < 0 ? 0 : nd.child1;
+                const bool sc = nd.token == sid, bin = nd.child1 >= 0;
+                const int y0 = N_[c0].token == sid ? pl->slot_Ysc + N_[c0].sample : pl->slot_Y + c0;
+                const int y1 = N_[c1].token == sid ? pl->slot_Ysc + N_[c1].sample : pl->slot_Y + c1;
+                const int in = sc ? pl->slot_F + nd.sample : bin ? pl->slot_P + pl->bin_index[v] : y0;
+                w[0] = bin ? y0 : in; w[1] = bin ? y1 : -1;
+                w[2] = sc ? pl->slot_Ysc + nd.sample : pl->slot_Y + v;
+                w[3] = sc ? pl->slot_Hsc + nd.sample : pl->slot_H + v;
+                w[4] = in; w[5] = -1; w[6] = -1; w[7] = nd.token;
+                w[8] = w[9] = w[10] = w[11] = -1;
+                w += 12;
             }
         }
     }
@@ -235,7 +245,7 @@ void build_forward_part(vqa_plan* pl) {
 // Backward half: input-gradient tile lists per level, per-sample sections, weight-gradient work
 // items.  Appended behind the forward half; nothing written earlier moves.
 void build_backward_part(vqa_plan* pl) {
-    std::vector<int32_t>& b = pl->blob;
+    PlanBlob& b = pl->blob;
     const int N = pl->N, NV = (int)pl->nodes.size(), V = pl->V, wgrad_chunk = pl->wgrad_chunk;
     const int scene_id = pl->scene_id;
     pl->finished = true;
@@ -470,54 +480,84 @@ static void balance_levels(vqa_plan* pl, int round, int scene_id) {
     if (L <= 2 || round <= 0) return;
     // Scene nodes stay at level 0 (one launch over the images, before anything else); the rest is
     // scheduled over levels 1..L-1.  A node may have several users (interned nodes of a shared
-    // image): users as a CSR list.
-    auto is_scene = [&](int v) { return pl->nodes[v].token == scene_id; };
-    std::vector<int> nuse(NV + 1, 0), pending(NV, 0), latest(NV, L - 1);
+    // image): users as a CSR list.  Which inputs a node has is as good as random to a branch
+    // predictor, so the passes over the nodes select instead of branching: an input that is absent
+    // or a scene node counts as input NV, a row of the tables that nothing reads.  The tables live in
+    // one scratch array that the plan keeps from build to build.
+    PlanNode* nodes = pl->nodes.data();
+    std::vector<int32_t>& w = pl->work;
+    w.resize((size_t)11 * NV + 2 * L + 16);
+    int32_t* e0 = w.data();              // [NV] first input that is scheduled here, or NV
+    int32_t* e1 = e0 + NV;               // [NV] second
+    int32_t* nuse = e1 + NV;             // [NV + 2] CSR row starts
+    int32_t* pending = nuse + NV + 2;    // [NV + 1] inputs not yet placed
+    int32_t* latest = pending + NV + 1;  // [NV + 1] last level the node may run in
+    int32_t* fill = latest + NV + 1;     // [NV + 1] CSR fill cursors
+    int32_t* users = fill + NV + 1;      // [2 NV] every node files itself twice, under NV if need be
+    int32_t* take = users + 2 * NV;      // [NV]
+    int32_t* next = take + NV;           // [NV + L] ready nodes: one first-in first-out chain per latest
+                                         // level, entry NV + b being the head of chain b
+    int32_t* tail = next + NV + L;       // [L]
+    std::fill(nuse, nuse + NV + 2, 0);
     for (int v = 0; v < NV; v++) {
-        const PlanNode& nd = pl->nodes[v];
-        for (int c : {nd.child0, nd.child1})
-            if (c >= 0 && !is_scene(c)) { nuse[c + 1]++; pending[v]++; }
+        const PlanNode& nd = nodes[v];
+        const int c0 = nd.child0, c1 = nd.child1;
+        const int ok0 = (c0 >= 0) & (nodes[c0 < 0 ? 0 : c0].token != scene_id);
+        const int ok1 = (c1 >= 0) & (nodes[c1 < 0 ? 0 : c1].token != scene_id);
+        const int a = ok0 ? c0 : NV, b = ok1 ? c1 : NV;
+        e0[v] = a; e1[v] = b;
+        nuse[a + 1]++; nuse[b + 1]++;
+        pending[v] = ok0 + ok1;
+        latest[v] = L - 1;
     }
-    for (int v = 0; v < NV; v++) nuse[v + 1] += nuse[v];
-    std::vector<int> users(nuse[NV]), fill(nuse.begin(), nuse.end() - 1);
+    latest[NV] = L - 1;
+    for (int v = 0; v <= NV; v++) { fill[v] = nuse[v]; nuse[v + 1] += nuse[v]; }
+    for (int v = 0; v < NV; v++) { users[fill[e0[v]]++] = v; users[fill[e1[v]]++] = v; }
+    for (int v = NV - 1; v >= 0; v--) {          // a user's id is larger than its inputs'
+        const int lv = latest[v] - 1;
+        latest[e0[v]] = std::min(latest[e0[v]], lv);
+        latest[e1[v]] = std::min(latest[e1[v]], lv);
+    }
+    for (int b = 0; b < L; b++) { next[NV + b] = -1; tail[b] = NV + b; }
+    auto push = [&](int v) {
+        const int b = latest[v];
+        next[v] = -1;
+        next[tail[b]] = v;
+        tail[b] = v;
+    };
+    int total = 0, nready = 0;
     for (int v = 0; v < NV; v++) {
-        const PlanNode& nd = pl->nodes[v];
-        for (int c : {nd.child0, nd.child1})
-            if (c >= 0 && !is_scene(c)) users[fill[c]++] = v;
+        const int mine = nodes[v].token != scene_id;
+        total += mine;
+        take[nready] = v;
+        nready += mine & (pending[v] == 0);
     }
-    for (int v = NV - 1; v >= 0; v--)            // a user's id is larger than its inputs'
-        for (int k = nuse[v]; k < nuse[v + 1]; k++) latest[v] = std::min(latest[v], latest[users[k]] - 1);
-    // ready nodes bucketed by latest level; within a bucket first in, first out
-    std::vector<std::vector<int>> bucket(L);
-    std::vector<size_t> head(L, 0);
-    int total = 0;
-    for (int v = 0; v < NV; v++) {
-        if (is_scene(v)) continue;
-        total++;
-        if (pending[v] == 0) bucket[latest[v]].push_back(v);
-    }
-    std::vector<int> take;
+    for (int i = 0; i < nready; i++) push(take[i]);
     int done = 0, lowest = 1;
     for (int t = 1; t < L; t++) {
         const int remaining = total - done, share = (remaining + (L - t) - 1) / (L - t);
         const int target = share <= round / 2 ? round / 2 : (share + round - 1) / round * round;
-        take.clear();
+        int ntake = 0;
         while (lowest < L) {
-            if (head[lowest] == bucket[lowest].size()) { lowest++; continue; }
-            if (lowest > t && (int)take.size() >= target) break;
-            take.push_back(bucket[lowest][head[lowest]++]);
+            const int v = next[NV + lowest];
+            if (v < 0) { lowest++; continue; }
+            if (lowest > t && ntake >= target) break;
+            next[NV + lowest] = next[v];
+            tail[lowest] = next[v] < 0 ? NV + lowest : tail[lowest];
+            take[ntake++] = v;
         }
-        for (int v : take) {
-            pl->nodes[v].level = t;
+        for (int i = 0; i < ntake; i++) {
+            const int v = take[i];
+            nodes[v].level = t;
             for (int k = nuse[v]; k < nuse[v + 1]; k++) {
                 const int p = users[k];
                 if (--pending[p] == 0) {
-                    bucket[latest[p]].push_back(p);
+                    push(p);
                     lowest = std::min(lowest, latest[p]);
                 }
             }
         }
-        done += (int)take.size();
+        done += ntake;
     }
 }
 
@@ -525,8 +565,8 @@ extern "C" int vqa_schedule_build(const int64_t* programs, int32_t N, int32_t T,
                                   const int8_t* arity, int32_t V, int32_t null_id,
                                   int32_t start_id, int32_t scene_id, int32_t C,
                                   int32_t wgrad_chunk, int32_t flags, vqa_plan** out) {
-    return vqa_schedule_build_shared(programs, N, T, arity, V, null_id, start_id, scene_id, C, wgrad_chunk,
-                                     flags, nullptr, N, out);
+    return vqa_schedule_build_into(programs, N, T, arity, V, null_id, start_id, scene_id, C, wgrad_chunk,
+                                   flags, nullptr, N, nullptr, 0, out);
 }
 
 extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int32_t T,
@@ -534,9 +574,20 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
                                          int32_t start_id, int32_t scene_id, int32_t C,
                                          int32_t wgrad_chunk, int32_t flags, const int32_t* image_of_sample,
                                          int32_t num_images, vqa_plan** out) {
+    return vqa_schedule_build_into(programs, N, T, arity, V, null_id, start_id, scene_id, C, wgrad_chunk,
+                                   flags, image_of_sample, num_images, nullptr, 0, out);
+}
+
+extern "C" int vqa_schedule_build_into(const int64_t* programs, int32_t N, int32_t T,
+                                       const int8_t* arity, int32_t V, int32_t null_id,
+                                       int32_t start_id, int32_t scene_id, int32_t C,
+                                       int32_t wgrad_chunk, int32_t flags, const int32_t* image_of_sample,
+                                       int32_t num_images, int32_t* blob_store, int64_t blob_store_words,
+                                       vqa_plan** out) {
     if (!programs || !arity || !out || N <= 0 || T <= 0 || V <= 0 || V > 255 || scene_id < 0 ||
         scene_id >= V || C <= 0 || C % 128 != 0 || wgrad_chunk <= 0 ||
-        (image_of_sample ? (num_images <= 0 || num_images >= (1 << 18)) : num_images != N)) {
+        (image_of_sample ? (num_images <= 0 || num_images >= (1 << 18)) : num_images != N) ||
+        (blob_store && blob_store_words < 0)) {
         vqa_set_error("vqa_schedule_build: bad argument");
         return VQA_EINVAL;
     }
@@ -571,34 +622,38 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     const int M = pl->M;
 
     const int NV = (int)pl->nodes.size();
-    // kind indices
-    pl->bin_index.assign(NV, -1);
-    pl->scene_index.assign(NV, -1);
-    int nb = 0, ns = 0, nu = 0, maxlev = 0;
-    pl->token_counts.assign(V, 0);
-    for (int v = 0; v < NV; v++) {
-        const PlanNode& nd = pl->nodes[v];
-        pl->token_counts[nd.token]++;
-        if (nd.token == scene_id) pl->scene_index[v] = ns++;
-        else if (nd.child1 >= 0) pl->bin_index[v] = nb++;
-        else nu++;
-        maxlev = std::max(maxlev, nd.level);
-    }
-    pl->num_scene = ns; pl->num_unary = nu; pl->num_binary = nb; pl->num_levels = maxlev + 1;
-
-    // Every scene node of an image computes the same map (same module, same input F): the first one
-    // runs, the others are aliases of it.  Node ids, and with them everything a caller indexes by
-    // node, stay as the reference's execution order numbers them.
+    // Kind indices, and the scene aliases: every scene node of an image computes the same map (same
+    // module, same input F), so the first one runs and the others stand for it.  Node ids, and with
+    // them everything a caller indexes by node, stay as the reference's execution order numbers them.
+    pl->bin_index.resize(NV);
+    pl->scene_index.resize(NV);
     pl->rep.resize(NV);
     pl->first_scene.assign(M, -1);
-    pl->num_exec = NV;
-    for (int v = 0; v < NV; v++) {
-        const PlanNode& nd = pl->nodes[v];
-        if (nd.token != scene_id) { pl->rep[v] = v; continue; }
-        if (pl->first_scene[nd.sample] < 0) pl->first_scene[nd.sample] = v;
-        pl->rep[v] = pl->first_scene[nd.sample];
-        if (pl->rep[v] != v) pl->num_exec--;
+    pl->token_counts.assign(V, 0);
+    int nb = 0, ns = 0, nu = 0, maxlev = 0, nexec = NV;
+    {
+        int32_t* bin_index = pl->bin_index.data();
+        int32_t* scene_index = pl->scene_index.data();
+        int32_t* rep = pl->rep.data();
+        int32_t* first_scene = pl->first_scene.data();
+        int32_t* token_counts = pl->token_counts.data();
+        for (int v = 0; v < NV; v++) {     // selects, not branches: the kinds come in no order
+            const PlanNode& nd = pl->nodes[v];
+            token_counts[nd.token]++;
+            const int sc = nd.token == scene_id, bin = nd.child1 >= 0;
+            const int fs = first_scene[nd.sample], nfs = (sc & (fs < 0)) ? v : fs;
+            first_scene[nd.sample] = nfs;
+            const int r = sc ? nfs : v;
+            scene_index[v] = sc ? ns : -1;
+            bin_index[v] = bin ? nb : -1;
+            rep[v] = r;
+            ns += sc; nb += bin; nu += 1 - sc - bin;
+            nexec -= r != v;
+            maxlev = std::max(maxlev, nd.level);
+        }
     }
+    pl->num_scene = ns; pl->num_unary = nu; pl->num_binary = nb; pl->num_levels = maxlev + 1;
+    pl->num_exec = nexec;
 
     if (flags & VQA_PLAN_BALANCE) balance_levels(pl, 512 / (C / 128), scene_id);
 
@@ -614,30 +669,44 @@ extern "C" int vqa_schedule_build_shared(const int64_t* programs, int32_t N, int
     pl->slots_total = pl->shared ? pl->slots_fwd : pl->slot_dS0 + M;
     pl->scene_id = scene_id; pl->wgrad_chunk = wgrad_chunk; pl->flags = flags;
 
-    // level buckets: nodes of a level sorted by (token, node id)
+    // level buckets: nodes of a level sorted by (token, node id) - one counting sort over
+    // (level, token) keys, which ascending node ids keep stable; the aliased scene nodes go to a key
+    // past the last level's
     if ((int)pl->level_nodes.size() < pl->num_levels) pl->level_nodes.resize(pl->num_levels);
     {
-        std::vector<int> cnt(pl->num_levels, 0);
-        for (int v = 0; v < NV; v++) if (pl->rep[v] == v) cnt[pl->nodes[v].level]++;
-        for (int L = 0; L < pl->num_levels; L++) pl->level_nodes[L].reserve(cnt[L]);
-    }
-    for (int v = 0; v < NV; v++) if (pl->rep[v] == v) pl->level_nodes[pl->nodes[v].level].push_back(v);
-    {   // stable counting sort of each level by token
-        std::vector<int> start(V + 1), tmp;
-        for (auto& lv : pl->level_nodes) {
-            std::fill(start.begin(), start.end(), 0);
-            for (int v : lv) start[pl->nodes[v].token + 1]++;
-            for (int t = 0; t < V; t++) start[t + 1] += start[t];
-            tmp.resize(lv.size());
-            for (int v : lv) tmp[start[pl->nodes[v].token]++] = v;
-            lv.swap(tmp);
+        const int NL = pl->num_levels, NK = NL * V;
+        std::vector<int32_t>& w = pl->work;
+        w.resize((size_t)NK + 1 + 2 * NV);
+        int32_t* pos = w.data();       // [NK + 1]
+        int32_t* key = pos + NK + 1;   // [NV]
+        int32_t* flat = key + NV;      // [NV]
+        std::fill(pos, pos + NK + 1, 0);
+        const int32_t* rep = pl->rep.data();
+        for (int v = 0; v < NV; v++) {
+            const PlanNode& nd = pl->nodes[v];
+            const int k = rep[v] == v ? nd.level * V + nd.token : NK;
+            key[v] = k;
+            pos[k]++;
         }
+        int at = 0;
+        for (int k = 0; k <= NK; k++) { const int n = pos[k]; pos[k] = at; at += n; }
+        for (int L = 0; L < NL; L++) pl->level_nodes[L].resize((L + 1 < NL ? pos[(L + 1) * V] : pos[NK]) - pos[L * V]);
+        const int first_alias = pos[NK];
+        for (int v = 0; v < NV; v++) flat[pos[key[v]]++] = v;
+        at = 0;
+        for (int L = 0; L < NL; L++) {
+            std::vector<int>& lv = pl->level_nodes[L];
+            if (!lv.empty()) std::memcpy(lv.data(), flat + at, lv.size() * sizeof(int));
+            at += (int)lv.size();
+        }
+        (void)first_alias;
     }
     pl->has_separate = !(flags & VQA_PLAN_SKIP_SEPARATE);
     pl->has_fused = !(flags & VQA_PLAN_SKIP_FUSED);
     // upper bound of the finished blob, so that a caller can size its buffers after the forward part
     pl->blob_bound = (size_t)NV * 88 + (size_t)N * 64 + (size_t)nb * 32 + (size_t)V * 32 + 1024;
-    pl->blob.reserve(pl->blob_bound);
+    if (blob_store && (size_t)blob_store_words >= pl->blob_bound) pl->blob.lend(blob_store, (size_t)blob_store_words);
+    else pl->blob.reserve(pl->blob_bound);
     build_forward_part(pl);
     pl->fwd_words = (int)pl->blob.size();
     pl->finished = pl->shared;      // forward-only plans have no backward part
@@ -664,6 +733,7 @@ extern "C" int vqa_plan_get_info(const vqa_plan* pl, vqa_plan_info* o) {
     o->num_levels = pl->num_levels;
     o->slots_fwd = pl->slots_fwd; o->slots_total = pl->slots_total;
     o->blob_words = (int)pl->blob.size();
+    o->blob_lent = pl->blob.lent() ? 1 : 0;
     o->wgrad_items = pl->sec_cnt[VQA_SEC_WG_ITEMS];
     o->max_level_tiles = pl->max_level_tiles;
     o->num_images = pl->M;

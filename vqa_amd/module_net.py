@@ -535,39 +535,51 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
                 # programs -> plan -> tile lists on the device
                 if arrived is not None:
                     arrived.synchronize()
+                # The device is about to run out of work (the stem and the scene level are short), so
+                # what stands between the programs and the first level's launch is kept to the
+                # scheduler itself: it writes the tile lists straight into pinned memory, their
+                # forward part goes up at once, and everything else that the plan feeds waits until
+                # the tree's launches are enqueued.  The backward part is written and sent after the
+                # forward launches.
+                want = Plan.blob_store_words(N, T, len(self.vocab['program_token_to_idx']))
+                host = ws.bufs.get('blob_host')
+                if host is None or host.numel() < want:
+                    host = ws.bufs['blob_host'] = torch.empty(want, dtype=torch.int32, pin_memory=True)
                 plan = Plan(hprog.numpy(), self.vocab, c, self.wgrad_chunk,
                             (_lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED) |
                             (_lib.PLAN_BALANCE if self.balance_levels and need_grad else 0) | _lib.PLAN_DEFER_BACKWARD,
-                            image_index=image_index, num_images=M if image_index is not None else None)
+                            image_index=image_index, num_images=M if image_index is not None else None,
+                            blob_store=host)
                 st['plan'] = plan
                 info = plan.info
-                self.last_token_counts = plan.token_counts()
-                if self.plan_ready_hook is not None:
-                    self.plan_ready_hook(self.last_token_counts, dev, need_grad)
-                # the forward part of the tile lists goes up now; the backward part is written and sent
-                # once the forward launches are enqueued (the host is what the device waits for here)
                 nb, bound = info.blob_words, info.blob_words_bound
-                host = ws.bufs.get('blob_host')
-                if host is None or host.numel() < bound:
-                    host = ws.bufs['blob_host'] = torch.empty(bound + bound // 4, dtype=torch.int32, pin_memory=True)
-                plan.blob_range_into(host, 0, nb)
-                hused = hp[:(N * T + 1) // 2].view(torch.float32)[:N * T].view(N, T)   # programs are parsed: reuse
-                plan.used_fns_into(hused)
+                if not info.blob_lent:
+                    plan.blob_range_into(host, 0, nb)
                 st['blob'] = ws.get('blob', bound, torch.int32, dev)
-                # Module_Model.py:227,231: a float tensor on the program's device
-                used = torch.empty(N, T, dtype=torch.float32, device=program.device)
                 with torch.cuda.stream(side):
                     st['blob'][:nb].copy_(host[:nb], non_blocking=True)
-                    if used.is_cuda:
-                        used.copy_(hused, non_blocking=True)
-                        used.record_stream(side)
-                    else:
-                        used.copy_(hused)
                     ws.host_event = torch.cuda.Event()
                     ws.host_event.record(side)
                 cur.wait_event(ws.host_event)
                 self._mark('blob')
-                self.used_fns = used
+
+                def after_tree():
+                    self.last_token_counts = plan.token_counts()
+                    if self.plan_ready_hook is not None:
+                        self.plan_ready_hook(self.last_token_counts, dev, need_grad)
+                    hused = hp[:(N * T + 1) // 2].view(torch.float32)[:N * T].view(N, T)   # programs are parsed: reuse
+                    plan.used_fns_into(hused)
+                    # Module_Model.py:227,231: a float tensor on the program's device
+                    used = torch.empty(N, T, dtype=torch.float32, device=program.device)
+                    if used.is_cuda:
+                        with torch.cuda.stream(side):
+                            used.copy_(hused, non_blocking=True)
+                            used.record_stream(side)
+                            ws.host_event = torch.cuda.Event()
+                            ws.host_event.record(side)
+                    else:
+                        used.copy_(hused)
+                    self.used_fns = used
                 slots = info.slots_total if need_grad else info.slots_fwd
                 arena_big = ws.get_capacity('arena', slots * HW * c, torch.bfloat16, dev)
                 if arena_big.data_ptr() != arena_full.data_ptr():     # grew: carry the stem output over
@@ -592,6 +604,7 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
             if fused:
                 tctx.flags |= _lib.TREE_SKIP_LEVEL0
             _lib.check(_lib.load().vqa_tree_forward(plan.handle, C.byref(tctx), ops._stream()))
+            after_tree()
         self._mark('tree_fwd')
         # classifier (Module_Model.py:66-93, default: no pooling): conv1x1 + ReLU on the gathered
         # roots, flatten, linear layers
@@ -644,7 +657,8 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
         if need_grad:
             plan.finish()
             total = plan.info.blob_words
-            plan.blob_range_into(host, nb, total - nb)
+            if not plan.info.blob_lent:
+                plan.blob_range_into(host, nb, total - nb)
             with torch.cuda.stream(side):
                 st['blob'][nb:total].copy_(host[nb:total], non_blocking=True)
                 ws.host_event = torch.cuda.Event()

@@ -11,35 +11,48 @@ import numpy as np
 from . import _lib, vocab as V
 
 
+# arity table per vocabulary object (rebuilt if its token table is replaced or grows)
+_ARITY = {}
+
+
 class Plan:
     """Parsed + bucketed programs of one batch.  Owns the native plan handle."""
 
-    def __init__(self, programs, vocab, module_dim=128, wgrad_chunk=16, flags=0, image_index=None, num_images=None):
+    def __init__(self, programs, vocab, module_dim=128, wgrad_chunk=16, flags=0, image_index=None, num_images=None,
+                 blob_store=None):
         """image_index: optional int array [N], the image each sample runs on; samples of one image
-        then share common subtrees and the plan is forward-only (vqa_schedule_build_shared)."""
+        then share common subtrees and the plan is forward-only (vqa_schedule_build_shared).
+        blob_store: optional int32 host tensor (pinned, say) that the tile lists are written into if
+        it is large enough (`blob_store_words`); `info.blob_lent` tells, and the tensor must then
+        outlive the plan."""
         lib = _lib.load()
         prog = np.ascontiguousarray(np.asarray(programs), dtype=np.int64)
         if prog.ndim != 2:
             raise ValueError('Unregonized program format')      # Module_Model.py:245
         t2i = vocab['program_token_to_idx']
-        arity = np.asarray(V.arity_table(vocab), dtype=np.int8)
+        cached = _ARITY.get(id(vocab))
+        if cached is None or cached[0] is not t2i or len(t2i) != len(cached[1]):
+            cached = _ARITY[id(vocab)] = (t2i, np.asarray(V.arity_table(vocab), dtype=np.int8))
+        arity = cached[1]
         self._lib = lib
         self._h = C.c_void_p()
         n, t = prog.shape
-        if image_index is None:
-            _lib.check(lib.vqa_schedule_build(
-                prog.ctypes.data_as(_lib.i64p), n, t, arity.ctypes.data_as(_lib.i8p), len(arity),
-                t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk, flags,
-                C.byref(self._h)))
-        else:
+        img, m = None, n
+        if image_index is not None:
             img = np.ascontiguousarray(np.asarray(image_index), dtype=np.int32)
             if img.shape != (n,):
                 raise ValueError('image_index must have one entry per program')
             m = int(num_images) if num_images is not None else int(img.max()) + 1
-            _lib.check(lib.vqa_schedule_build_shared(
-                prog.ctypes.data_as(_lib.i64p), n, t, arity.ctypes.data_as(_lib.i8p), len(arity),
-                t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk, flags,
-                img.ctypes.data_as(_lib.i32p), m, C.byref(self._h)))
+        store, store_words = None, 0
+        if blob_store is not None:
+            assert blob_store.dtype.itemsize == 4 and blob_store.is_contiguous()
+            store, store_words = C.cast(blob_store.data_ptr(), _lib.i32p), blob_store.numel()
+        self._store = blob_store
+        _lib.check(lib.vqa_schedule_build_into(
+            prog.ctypes.data_as(_lib.i64p), n, t, arity.ctypes.data_as(_lib.i8p), len(arity),
+            t2i['<NULL>'], t2i['<START>'], t2i['scene'], module_dim, wgrad_chunk, flags,
+            img.ctypes.data_as(_lib.i32p) if img is not None else None, m, store, store_words,
+            C.byref(self._h)))
         self.info = _lib.PlanInfo()
         _lib.check(lib.vqa_plan_get_info(self._h, C.byref(self.info)))
         self.N, self.T, self.C = n, t, module_dim
@@ -54,6 +67,11 @@ class Plan:
     @property
     def handle(self):
         return self._h
+
+    @staticmethod
+    def blob_store_words(n, t, vocab_size):
+        """Words that a blob_store needs for any n programs of t tokens."""
+        return n * (t + 1) * 88 + n * 64 + n * (t + 1) // 2 * 32 + vocab_size * 32 + 1024
 
     def used_fns(self):
         out = np.empty((self.N, self.T), dtype=np.float32)
