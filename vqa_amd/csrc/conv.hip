@@ -1,12 +1,15 @@
 // Grouped implicit-GEMM convolution over 14x14 feature-map tiles (gfx950, bf16 MFMA).
 //
-// One workgroup (4 waves) = one tile = one feature map (14 image rows, each one MFMA column tile of
-// 16 lanes of which 14 are pixels: 16 consecutive pixels would straddle image rows and make every
-// LDS fragment read a 2-way bank conflict) x 128 output channels; wave w owns output channels
-// [32w, 32w+32).
+// One workgroup (4 waves) = one tile = one feature map x 128 output channels; wave w owns output
+// channels [32w, 32w+32).  The map's 196 pixels are 13 MFMA column tiles of 16 consecutive pixels
+// (the last one has 4): a tile per image row, 14 pixels in 16 lanes, would spend a fourteenth tile's
+// MFMAs and LDS reads on lanes that hold nothing.
 //   * pixels: for each 128-channel source chunk the map is staged once into an LDS halo image
 //     (16 x 16 positions, zero border, 288-byte position stride); the 9 taps are 9 address offsets
-//     into that image, so the im2col matrix never exists
+//     into that image, so the im2col matrix never exists.  Image rows are 16 positions + 192 bytes
+//     apart: from the last pixel of an image row to the first of the next the address then moves by
+//     one position stride modulo the 256 bytes of a bank row, so the 16 pixels of a tile, which
+//     straddle image rows, fall on the banks like 16 consecutive positions: no conflict
 //   * weights: every wave streams its own fragments straight from L2 into registers, one
 //     coalesced 1 KiB load per 16 x 32 fragment, 4 K-steps ahead; the packed layout is
 //     fragment-major so no LDS, no barrier and no bank conflict is spent on them
@@ -21,11 +24,12 @@
 #include "plan.h"
 #include "prof.h"
 
-#define HALO_STRIDE 288
-#define HALO_POS 264
-#define HALO_BYTES (HALO_POS * HALO_STRIDE)   // 76032
+#define HALO_STRIDE 288                       // bytes per position
+#define HALO_ROW (16 * HALO_STRIDE + 192)     // bytes per image row: 4800
+#define HALO_BYTES (16 * HALO_ROW - 192)      // 76608: 16 rows of 16 positions
+#define HALO_CENTER (HALO_ROW + HALO_STRIDE)  // from a pixel's (-1,-1) neighbour to the pixel itself
 #define CONV_LDS HALO_BYTES
-#define MT 14                                 // pixel tiles = image rows
+#define MT 13                                 // pixel tiles: 16 consecutive pixels each
 
 // ---------------------------------------------------------------------------------------------
 // Building blocks shared by the single-conv kernel and the fused residual-body kernel
@@ -41,18 +45,36 @@ __device__ __forceinline__ int xcd_tile_index(int block, int n) {
     return x * q + min(x, r) + j;
 }
 
-// zero the border of the halo image: the 68 positions no staging pass ever writes (row 0, columns
-// 0 and 15 of rows 1..14, rows 15 and 16)
+// byte offset of border position j of the halo image: the 60 positions no staging pass ever writes
+// (row 0, columns 0 and 15 of rows 1..14, row 15)
+#define HALO_BORDER 60
+__device__ __forceinline__ int halo_border_at(int j) {
+    if (j < 16) return j * HALO_STRIDE;
+    if (j < 44) return (((j - 16) >> 1) + 1) * HALO_ROW + ((j & 1) ? 15 * HALO_STRIDE : 0);
+    return 15 * HALO_ROW + (j - 44) * HALO_STRIDE;
+}
+
 __device__ __forceinline__ void halo_zero_border(char* halo, int tid) {
-    for (int idx = tid; idx < 68 * 16; idx += 256) {
-        const int j = idx >> 4;
-        int pos;
-        if (j < 16) pos = j;
-        else if (j < 44) pos = (((j - 16) >> 1) + 1) * 16 + ((j & 1) ? 15 : 0);
-        else pos = 240 + (j - 44);
-        *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+    for (int idx = tid; idx < HALO_BORDER * 16; idx += 256)
+        *(uint4*)(halo + halo_border_at(idx >> 4) + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+}
+
+// This lane's pixel of every pixel tile: tile m, lane column l15 -> pixel 16 m + l15 (tile 12: lanes 0..3).
+// xaddr[m] = byte offset of the pixel's (-1,-1) neighbour in the halo image, K-chunk lq: tap (dy, dx) is
+// dy * HALO_ROW + dx * HALO_STRIDE further, the pixel's own cell HALO_CENTER further.  The 12 lanes
+// without a pixel read pixel 4's cells (one address: a broadcast, on banks no lane with a pixel is
+// on) and their results are never stored.
+__device__ __forceinline__ void lane_pixels(int (&xaddr)[MT], int l15, int lq) {
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        int px = m * 16 + l15;
+        if (m == MT - 1 && l15 >= 4) px = 4;
+        const int y = px / 14, x = px - y * 14;
+        xaddr[m] = y * HALO_ROW + x * HALO_STRIDE + lq * 16;
     }
 }
+// whether this lane's column holds a pixel in tile m
+__device__ __forceinline__ bool lane_has_pixel(int m, int l15) { return m < MT - 1 || l15 < 4; }
 
 // copy one 128-channel chunk of a source map (196 pixels x 256 B) into the halo image interior,
 // through registers, 7 image rows at a time; thread = (image column x = tid >> 4, 16-byte piece
@@ -61,7 +83,7 @@ __device__ __forceinline__ void halo_stage(char* halo, const char* sp, int pix_s
     const int x = tid >> 4, pc = tid & 15;
     const bool active = x < 14;
     const char* g = sp + (int64_t)(active ? x : 0) * pix_stride_bytes + pc * 16;
-    char* cell = halo + (16 + x + 1) * HALO_STRIDE + pc * 16;
+    char* cell = halo + HALO_ROW + (x + 1) * HALO_STRIDE + pc * 16;
 #pragma unroll 1
     for (int y0 = 0; y0 < 14; y0 += 7) {
         uint4 v[7];
@@ -72,49 +94,52 @@ __device__ __forceinline__ void halo_stage(char* halo, const char* sp, int pix_s
         }
         if (active) {
 #pragma unroll
-            for (int i = 0; i < 7; i++) *(uint4*)(cell + (y0 + i) * 16 * HALO_STRIDE) = v[i];
+            for (int i = 0; i < 7; i++) *(uint4*)(cell + (y0 + i) * HALO_ROW) = v[i];
         }
     }
 }
 
-// K loop over one 128-channel chunk already staged in the halo image: TAPS x 4 K-steps x 14 pixel
+// K loop over one 128-channel chunk already staged in the halo image: TAPS x 4 K-steps x 13 pixel
 // tiles.  Weights come through the 4-slot register ring `wr` (refilled for K-step s+4 after use,
 // so three K-steps of MFMAs cover the L2 latency); pixel fragments through an 8-deep ring read 7
 // tiles ahead; the issue order is pinned to 1 LDS read : 2 MFMA (left alone, the scheduler collapses
-// the ring and waits on every read right after issuing it).  With ZERO the accumulators start from
-// the first K-step's products plus `c0` (the C operand of those MFMAs: this lane's bias values, or zeros)
-// instead of from registers somebody cleared - the bias costs no instruction of its own anywhere.
+// the ring and waits on every read right after issuing it).  A tap is 52 fragments, half a turn of
+// the ring more than a whole number: taps alternate between two phases of the ring.  With ZERO the accumulators start from the first K-step's products plus `c0`
+// (the C operand of those MFMAs: this lane's bias values, or zeros) instead of from registers
+// somebody cleared - the bias costs no instruction of its own anywhere.
 template <int TAPS, bool ZERO>
 __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[MT], const char* wbase, int64_t wstep,
                                            int nsteps, int& s, bf16x8 (&wr)[4][2], f32x4 (&acc)[MT][2],
                                            const f32x4 (&c0)[2], bool diag_now) {
     bf16x8 xq[8];
     {
-        const char* x0 = halo + ((TAPS == 9) ? 0 : 17) * HALO_STRIDE;
+        const char* x0 = halo + ((TAPS == 9) ? 0 : HALO_CENTER);
 #pragma unroll
         for (int q = 0; q < 7; q++) xq[q] = *(const bf16x8*)(x0 + xaddr[q]);
     }
-    auto tap_body = [&](int tap, auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const int tapoff = (TAPS == 9) ? ((tap / 3) * 16 + (tap % 3)) : 17;
-        const int tn = (tap + 1 < TAPS) ? tap + 1 : tap;      // last tap: harmless re-read
-        const int tapoff_n = (TAPS == 9) ? ((tn / 3) * 16 + (tn % 3)) : 17;
-        const char* xb = halo + tapoff * HALO_STRIDE;
-        const char* xn = halo + tapoff_n * HALO_STRIDE;
+    auto tap_body = [&](auto tap_tag) {
+        constexpr int tap = decltype(tap_tag)::value;
+        constexpr bool FIRST = ZERO && tap == 0;
+        constexpr int PH = (tap & 1) * 4;                      // ring slot of the tap's first fragment
+        constexpr int tapoff = (TAPS == 9) ? ((tap / 3) * HALO_ROW + (tap % 3) * HALO_STRIDE) : HALO_CENTER;
+        constexpr int tn = (tap + 1 < TAPS) ? tap + 1 : tap;  // last tap: harmless re-read
+        constexpr int tapoff_n = (TAPS == 9) ? ((tn / 3) * HALO_ROW + (tn % 3) * HALO_STRIDE) : HALO_CENTER;
+        const char* xb = halo + tapoff;
+        const char* xn = halo + tapoff_n;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++, s++) {
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-                const int q = ks * MT + m;            // 0..55 within the tap
+                const int q = ks * MT + m;            // 0..51 within the tap
                 const int qa = q + 7;                 // fragment to fetch now
                 const int ka = (qa / MT) & 3, ma = qa % MT;
-                xq[qa & 7] = *(const bf16x8*)((qa < 4 * MT ? xb : xn) + xaddr[ma] + ka * 64);
+                xq[(qa + PH) & 7] = *(const bf16x8*)((qa < 4 * MT ? xb : xn) + xaddr[ma] + ka * 64);
                 if (FIRST && ks == 0) {
-                    acc[m][0] = mma16(wr[ks][0], xq[q & 7], c0[0]);
-                    acc[m][1] = mma16(wr[ks][1], xq[q & 7], c0[1]);
+                    acc[m][0] = mma16(wr[ks][0], xq[(q + PH) & 7], c0[0]);
+                    acc[m][1] = mma16(wr[ks][1], xq[(q + PH) & 7], c0[1]);
                 } else {
-                    acc[m][0] = mma16(wr[ks][0], xq[q & 7], acc[m][0]);
-                    acc[m][1] = mma16(wr[ks][1], xq[q & 7], acc[m][1]);
+                    acc[m][0] = mma16(wr[ks][0], xq[(q + PH) & 7], acc[m][0]);
+                    acc[m][1] = mma16(wr[ks][1], xq[(q + PH) & 7], acc[m][1]);
                 }
             }
 #pragma unroll
@@ -128,17 +153,24 @@ __device__ __forceinline__ void conv_kloop(const char* halo, const int (&xaddr)[
             __builtin_amdgcn_sched_barrier(0);   // keep the refill here: sunk to the loop end it is waited on at once
         }
     };
-    if (ZERO) tap_body(0, std::true_type{});
-#pragma unroll 1
-    for (int tap = ZERO ? 1 : 0; tap < TAPS; tap++) tap_body(tap, std::false_type{});
+    static_assert((4 * MT) % 8 == 4, "the two ring phases assume a tap of 8 n + 4 fragments");
+    // (taps unrolled: a tap's offset is then part of every read's immediate offset; added at run time it
+    // would need a register per pixel tile and tap in flight)
+    tap_body(std::integral_constant<int, 0>{});
+    if constexpr (TAPS == 9) {
+        tap_body(std::integral_constant<int, 1>{}); tap_body(std::integral_constant<int, 2>{});
+        tap_body(std::integral_constant<int, 3>{}); tap_body(std::integral_constant<int, 4>{});
+        tap_body(std::integral_constant<int, 5>{}); tap_body(std::integral_constant<int, 6>{});
+        tap_body(std::integral_constant<int, 7>{}); tap_body(std::integral_constant<int, 8>{});
+    }
 }
 
-// Final epilogue.  A lane holds pixel (m, l15) x 4 channels, i.e. 8-byte pieces scattered over 14
-// cache lines per instruction; written, or worse read (residual, mask), that way the epilogue costs
-// more than the K loop.  So the raw accumulators go through LDS (fp32, 7 image rows at a time, the
-// halo image is dead by now) and come back pixel-major: every global access is 16 bytes per lane,
-// 1 KiB contiguous per wave, and residual, rounding, ReLU and mask are applied there, two
-// channels per instruction (the bias is in the accumulators since the first K-step).
+// Final epilogue.  A lane holds 4 channels of one pixel per tile, i.e. 8-byte pieces scattered over
+// 16 cache lines per instruction; written, or worse read (residual, mask), that way the epilogue costs
+// more than the K loop.  So the raw accumulators go through LDS (fp32, tiles 0..6 = pixels 0..111,
+// then tiles 7..12 = pixels 112..195; the halo image is dead by now) and come back pixel-major: every
+// global access is 16 bytes per lane, 1 KiB contiguous per wave, and residual, rounding, ReLU and mask
+// are applied there, two channels per instruction (the bias is in the accumulators since the first K-step).
 //   out = [relu]( acc + res ) * (mask > 0)
 template <bool RES, bool MASK>
 __device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[MT][2], bool relu,
@@ -146,34 +178,36 @@ __device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[M
                                                 int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     const int pc = tid & 15;            // this thread's 16-byte column of every row: channels 8*pc..8*pc+7
-    float* stg = (float*)halo;          // [98 pixels][132 floats]: 528-byte rows keep the writes conflict-free
+    float* stg = (float*)halo;          // [112 pixels][132 floats]: 528-byte rows keep the writes conflict-free
     // (a generic lambda called with a constant: a run-time `half` would select between accumulator
     // registers with one v_cndmask per value)
     auto do_half = [&](auto half_tag) {
         constexpr int half = decltype(half_tag)::value;
-        // this thread's 16-byte pieces of the half: piece i -> pixel 98*half + (tid >> 4) + 16*i
-        const int64_t g0 = ((int64_t)(98 * half + (tid >> 4)) * pix_stride + pc * 8) * 2;
-        uint4 rv[7], mv[7];
+        constexpr int tiles = half ? MT - 7 : 7;
+        // this thread's 16-byte pieces of the half: piece i -> pixel 112*half + (tid >> 4) + 16*i
+        const int p0 = 112 * half + (tid >> 4);
+        const int64_t g0 = ((int64_t)p0 * pix_stride + pc * 8) * 2;
+        uint4 rv[tiles], mv[tiles];
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const int64_t goff = g0 + (i < 6 || (tid >> 4) < 2 ? (int64_t)i * 16 * pix_stride * 2 : 0);
+        for (int i = 0; i < tiles; i++) {
+            const int64_t goff = g0 + (p0 + 16 * i < VQA_HW ? (int64_t)i * 16 * pix_stride * 2 : 0);
             if (RES) rv[i] = *(const uint4*)(rsrc + goff);
             if (MASK) mv[i] = *(const uint4*)(msrc + goff);
         }
         lds_barrier();       // K loop reads (half 0) / previous half's staging reads are done
-        if (l15 < 14) {
+        {
             float* row = stg + l15 * 132 + wave * 32 + lq * 4;
 #pragma unroll
-            for (int mm = 0; mm < 7; mm++) {
-                *(f32x4*)(row + mm * 14 * 132) = acc[7 * half + mm][0];
-                *(f32x4*)(row + mm * 14 * 132 + 16) = acc[7 * half + mm][1];
+            for (int mm = 0; mm < tiles; mm++) {
+                *(f32x4*)(row + mm * 16 * 132) = acc[7 * half + mm][0];
+                *(f32x4*)(row + mm * 16 * 132 + 16) = acc[7 * half + mm][1];
             }
         }
         lds_barrier();
         const float* src = stg + (tid >> 4) * 132 + pc * 8;
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-            if (i < 6 || (tid >> 4) < 2) {       // pixel (tid >> 4) + 16 i < 98
+        for (int i = 0; i < tiles; i++) {
+            if (p0 + 16 * i < VQA_HW) {
                 const f32x4 f0 = *(const f32x4*)(src + i * 16 * 132);
                 const f32x4 f1 = *(const f32x4*)(src + i * 16 * 132 + 4);
                 f32x2 o[4] = {{f0[0], f0[1]}, {f0[2], f0[3]}, {f1[0], f1[1]}, {f1[2], f1[3]}};
@@ -244,11 +278,14 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 
     f32x4 acc[MT][2];
     // LDS byte offset of this lane's pixel in every pixel tile, at tap (-1,-1), K-chunk lq
-    // (lanes 14, 15 read halo padding; their results are discarded)
     int xaddr[MT];
-#pragma unroll
-    for (int m = 0; m < MT; m++) xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
+    lane_pixels(xaddr, l15, lq);
 
+    // (the accumulators start from the bias here, not in the first K-step's MFMAs: two copies of the K loop
+    // in the chunk loop, one per form, begin alike, and the compiler then moves their common reads in
+    // front of the branch - twenty fragments in flight and their registers spilled)
+#pragma unroll
+    for (int m = 0; m < MT; m++) { acc[m][0] = binit[0]; acc[m][1] = binit[1]; }
     int s = 0;
     for (int c = 0; c < p.k_chunks; c++) {
         int slot, choff;
@@ -258,8 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
         __syncthreads();   // every wave is done reading the previous chunk's image
         halo_stage(halo, sp, p.src_pix_stride * 2, tid, (p.flags & 0x400) != 0);
         __syncthreads();
-        if (c == 0) conv_kloop<TAPS, true>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, binit, (p.flags & 0x200) != 0);
-        else conv_kloop<TAPS, false>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, binit, (p.flags & 0x200) != 0);
+        conv_kloop<TAPS, false>(halo, xaddr, wbase, wstep, nsteps, s, wr, acc, binit, (p.flags & 0x200) != 0);
     }
 
     if (p.flags & 0x100) {   // diagnostic: skip the epilogue
@@ -325,11 +361,10 @@ __global__ __launch_bounds__(512, 1) void stem_nchw_kernel(vqa_stem_params p) {
     const int k_chunks = p.Cin >> 7;
     char* const img2 = halo + HALO_BYTES;
     // borders of both images, by everybody
-    for (int idx = tid; idx < 68 * 16; idx += 512) {
-        const int j = idx >> 4;
-        const int pos = j < 16 ? j : (j < 44 ? (((j - 16) >> 1) + 1) * 16 + ((j & 1) ? 15 : 0) : 240 + (j - 44));
-        *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
-        *(uint4*)(img2 + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+    for (int idx = tid; idx < HALO_BORDER * 16; idx += 512) {
+        const int at = halo_border_at(idx >> 4) + (idx & 15) * 16;
+        *(uint4*)(halo + at) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(img2 + at) = make_uint4(0, 0, 0, 0);
     }
     if (wave >= 4) {
         // ---------------- producers ----------------
@@ -365,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void stem_nchw_kernel(vqa_stem_params p) {
             const int px = (k >> 1) * 128 + (k & 1) * 64 + grp * 16 + l15;
             ok[k] = px < VQA_HW;
             const int pc = ok[k] ? px : 0, y = pc / 14, x = pc - y * 14;
-            cell[k] = ((y + 1) * 16 + x + 1) * HALO_STRIDE;
+            cell[k] = (y + 1) * HALO_ROW + (x + 1) * HALO_STRIDE;
         }
         bf16_t* xn = p.x_nhwc ? (bf16_t*)p.x_nhwc + (int64_t)n * VQA_HW * p.Cin : nullptr;
         // Group gq of chunk c: 8 of the wave's 32 planes.  One group is in flight while the one before it is
@@ -442,11 +477,11 @@ __global__ __launch_bounds__(512, 1) void stem_nchw_kernel(vqa_stem_params p) {
                 // 256-byte rows: thread = (image column, 16-byte piece), 14 image rows
                 const int ptid = tid - 256, cx = ptid >> 4, pcs = ptid & 15;
                 if (cx < 14) {
-                    const char* im = ((c & 1) ? img2 : halo) + (16 + cx + 1) * HALO_STRIDE + pcs * 16;
+                    const char* im = ((c & 1) ? img2 : halo) + HALO_ROW + (cx + 1) * HALO_STRIDE + pcs * 16;
                     bf16_t* o = xn + (int64_t)cx * p.Cin + c * 128 + pcs * 8;
 #pragma unroll
                     for (int y = 0; y < 14; y++)
-                        *(uint4*)(o + (int64_t)y * 14 * p.Cin) = *(const uint4*)(im + y * 16 * HALO_STRIDE);
+                        *(uint4*)(o + (int64_t)y * 14 * p.Cin) = *(const uint4*)(im + y * HALO_ROW);
                 }
             }
         }
@@ -468,8 +503,7 @@ __global__ __launch_bounds__(512, 1) void stem_nchw_kernel(vqa_stem_params p) {
     f32x4 binit[2];
     lane_bias(binit, p.bias, wave, lq);
     int xaddr[MT];
-#pragma unroll
-    for (int m = 0; m < MT; m++) xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
+    lane_pixels(xaddr, l15, lq);
     f32x4 acc[MT][2];
     int s = 0;
     lds_barrier();
@@ -477,13 +511,13 @@ __global__ __launch_bounds__(512, 1) void stem_nchw_kernel(vqa_stem_params p) {
 #pragma unroll 1
     for (int c = 1; c < k_chunks; c++) {
         lds_barrier();
-        // (the image's base goes into the lane's address register, made opaque: every read of the K loop is then
-        // that register plus a constant that fits the instruction's offset field)
-        int lb = l15 * HALO_STRIDE + lq * 16 + (c & 1) * HALO_BYTES;
-        asm volatile("" : "+v"(lb));
+        // (the image's base goes into the lane's address registers, made opaque: every read of the K loop is then
+        // a register plus a constant that fits the instruction's offset field)
+        int ib = (c & 1) * HALO_BYTES;
+        asm volatile("" : "+v"(ib));
         int xa[MT];
 #pragma unroll
-        for (int m = 0; m < MT; m++) xa[m] = m * 16 * HALO_STRIDE + lb;
+        for (int m = 0; m < MT; m++) xa[m] = xaddr[m] + ib;
         conv_kloop<9, false>(halo, xa, wbase, wstep, nsteps, s, wr, acc, binit, false);
     }
     char* dptr = (char*)p.dst + (int64_t)(p.dst_slot_first + n) * p.dst_slot_stride * 2;
@@ -536,7 +570,7 @@ __device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
 // accumulators (the bias is in them) [ReLU] -> bf16 -> interior of the halo image; then a row-wise pass
 // applies an optional mask, rewrites the image and stores the map to `dst` in 16-byte pieces.
 template <bool MASK>
-__device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT][2], bool relu,
+__device__ __forceinline__ void acc_to_image_t(char* halo, const int (&xaddr)[MT], const f32x4 (&acc)[MT][2], bool relu,
                                                const char* mask, char* dst, int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     // row pass mapping: thread = (image column x = tid >> 4, 16-byte piece pc = tid & 15), looping over
@@ -554,7 +588,8 @@ __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT
     {
         // 16-byte conflict-free LDS writes after a swap between the lane rows: see solo_epilogue_t
         const uint32_t floor_pk = relu ? 0u : 0x80008000u;
-        char* cell = halo + (16 + l15 + 1) * HALO_STRIDE + (wave * 32 + 16 * (lq & 1) + 8 * (lq >> 1)) * 2;
+        // this lane's pixel: its own cell, the 8 channels the swap leaves the lane with
+        char* cell = halo + HALO_CENTER - lq * 16 + (wave * 32 + 16 * (lq & 1) + 8 * (lq >> 1)) * 2;
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             const f32x4 o0 = acc[m][0], o1 = acc[m][1];
@@ -564,19 +599,19 @@ __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT
             uint32_t c1 = max_pk_i16(cvt_pk_bf16((f32x2){o1[2], o1[3]}), floor_pk);
             swap16(a0, c0);
             swap16(a1, c1);
-            if (l15 < 14) *(uint4*)(cell + m * 16 * HALO_STRIDE) = make_uint4(a0, a1, c0, c1);
+            if (lane_has_pixel(m, l15)) *(uint4*)(cell + xaddr[m]) = make_uint4(a0, a1, c0, c1);
         }
     }
     lds_barrier();
     if (active) {
-        char* cell = halo + (16 + x + 1) * HALO_STRIDE + pc * 16;
+        char* cell = halo + HALO_ROW + (x + 1) * HALO_STRIDE + pc * 16;
 #pragma unroll
         for (int y = 0; y < 14; y++) {
-            uint4 v = *(uint4*)(cell + y * 16 * HALO_STRIDE);
+            uint4 v = *(uint4*)(cell + y * HALO_ROW);
             if (MASK) {
                 v = make_uint4(mask_pk_bf16(v.x, mv[y].x), mask_pk_bf16(v.y, mv[y].y), mask_pk_bf16(v.z, mv[y].z),
                                mask_pk_bf16(v.w, mv[y].w));
-                *(uint4*)(cell + y * 16 * HALO_STRIDE) = v;
+                *(uint4*)(cell + y * HALO_ROW) = v;
             }
             *(uint4*)(dst + goff + y * 14 * 256) = v;
         }
@@ -584,10 +619,10 @@ __device__ __forceinline__ void acc_to_image_t(char* halo, const f32x4 (&acc)[MT
     lds_barrier();
 }
 
-__device__ __forceinline__ void acc_to_image(char* halo, const f32x4 (&acc)[MT][2], bool relu,
+__device__ __forceinline__ void acc_to_image(char* halo, const int (&xaddr)[MT], const f32x4 (&acc)[MT][2], bool relu,
                                              const char* mask, char* dst, int tid) {
-    if (mask) acc_to_image_t<true>(halo, acc, relu, mask, dst, tid);
-    else acc_to_image_t<false>(halo, acc, relu, mask, dst, tid);
+    if (mask) acc_to_image_t<true>(halo, xaddr, acc, relu, mask, dst, tid);
+    else acc_to_image_t<false>(halo, xaddr, acc, relu, mask, dst, tid);
 }
 
 __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase, int64_t wstep) {
@@ -614,7 +649,7 @@ __device__ __forceinline__ void load_wring(bf16x8 (&wr)[4][2], const char* wbase
 // residual map is read the same way and swapped back into the accumulator layout.
 // No barrier in front of the writes: `img` is an image nobody reads at this point (the caller's rule).
 template <bool MASK, bool RES, bool KEEP>
-__device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, const f32x4 (&acc)[MT][2],
+__device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, const int (&xaddr)[MT], const f32x4 (&acc)[MT][2],
                                                 bool relu, const char* mask, char* dst, int tid) {
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     const int x = tid >> 4, pc = tid & 15;
@@ -630,19 +665,20 @@ __device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, con
     {
         // ReLU without a branch per row: a signed 16-bit maximum with 0, or with the most negative value (no change)
         const uint32_t floor_pk = relu ? 0u : 0x80008000u;
-        // lanes 14 and 15 of a row stand on the zero border: they read it (zeros) but never write
-        const int celloff = (16 + l15 + 1) * HALO_STRIDE + (wave * 32 + 16 * (lq & 1) + 8 * (lq >> 1)) * 2;
+        // this lane's pixel: its own cell (xaddr[m] further), the 8 channels the swap leaves the lane with;
+        // lanes without a pixel read pixel 4's cell and never write
+        const int celloff = HALO_CENTER - lq * 16 + (wave * 32 + 16 * (lq & 1) + 8 * (lq >> 1)) * 2;
         char* cell = img + celloff;
         // the residual cells are read three image rows ahead (all 14 at once: 56 registers too many next to
         // the mask rows); the order is pinned row by row, or the scheduler hoists every read to the top
         uint4 xr[MT];
         if (RES) {
 #pragma unroll
-            for (int m = 0; m < 3; m++) xr[m] = *(const uint4*)(xres + celloff + m * 16 * HALO_STRIDE);
+            for (int m = 0; m < 3; m++) xr[m] = *(const uint4*)(xres + celloff + xaddr[m]);
         }
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            if (RES && m + 3 < MT) xr[m + 3] = *(const uint4*)(xres + celloff + (m + 3) * 16 * HALO_STRIDE);
+            if (RES && m + 3 < MT) xr[m + 3] = *(const uint4*)(xres + celloff + xaddr[m + 3]);
             f32x4 o0 = acc[m][0], o1 = acc[m][1];
             if (RES) {
                 swap16(xr[m].x, xr[m].z);
@@ -658,20 +694,20 @@ __device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, con
             uint32_t c1 = max_pk_i16(cvt_pk_bf16((f32x2){o1[2], o1[3]}), floor_pk);
             swap16(a0, c0);
             swap16(a1, c1);
-            if (l15 < 14) *(uint4*)(cell + m * 16 * HALO_STRIDE) = make_uint4(a0, a1, c0, c1);
+            if (lane_has_pixel(m, l15)) *(uint4*)(cell + xaddr[m]) = make_uint4(a0, a1, c0, c1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     lds_barrier();
     if (active) {
-        char* cell = img + (16 + x + 1) * HALO_STRIDE + pc * 16;
+        char* cell = img + HALO_ROW + (x + 1) * HALO_STRIDE + pc * 16;
 #pragma unroll
         for (int y = 0; y < 14; y++) {
-            uint4 v = *(uint4*)(cell + y * 16 * HALO_STRIDE);
+            uint4 v = *(uint4*)(cell + y * HALO_ROW);
             if (MASK) {
                 v = make_uint4(mask_pk_bf16(v.x, mv[y].x), mask_pk_bf16(v.y, mv[y].y), mask_pk_bf16(v.z, mv[y].z),
                                mask_pk_bf16(v.w, mv[y].w));
-                if (KEEP) *(uint4*)(cell + y * 16 * HALO_STRIDE) = v;
+                if (KEEP) *(uint4*)(cell + y * HALO_ROW) = v;
             }
             *(uint4*)(dst + goff + y * 14 * 256) = v;
         }
@@ -680,10 +716,10 @@ __device__ __forceinline__ void solo_epilogue_t(char* img, const char* xres, con
 }
 
 template <bool RES, bool KEEP>
-__device__ __forceinline__ void solo_epilogue(char* img, const char* xres, const f32x4 (&acc)[MT][2],
+__device__ __forceinline__ void solo_epilogue(char* img, const char* xres, const int (&xaddr)[MT], const f32x4 (&acc)[MT][2],
                                               bool relu, const char* mask, char* dst, int tid) {
-    if (mask) solo_epilogue_t<true, RES, KEEP>(img, xres, acc, relu, mask, dst, tid);
-    else solo_epilogue_t<false, RES, KEEP>(img, xres, acc, relu, mask, dst, tid);
+    if (mask) solo_epilogue_t<true, RES, KEEP>(img, xres, xaddr, acc, relu, mask, dst, tid);
+    else solo_epilogue_t<false, RES, KEEP>(img, xres, xaddr, acc, relu, mask, dst, tid);
 }
 
 // RANGE false: one tile per workgroup, entry blockIdx.x of the list in XCD order.  RANGE true: the
@@ -725,8 +761,8 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
         // (the second image is beyond the reach of the LDS instructions' 16-bit offsets from the first image's
         // lane address: its own lane address, opaque to constant folding, keeps the K loops' reads free of adds.
         // Made here: a volatile statement between the two halves of the staging below sends its 14 rows through scratch)
-        int lane2 = l15 * HALO_STRIDE + lq * 16 + HALO_BYTES;
-        asm volatile("" : "+v"(lane2));
+        int base2 = HALO_BYTES;
+        asm volatile("" : "+v"(base2));
         bf16x8 wr[4][2];
         load_wring(wr, wbase, wstep_pre);
         f32x4 b_pre[2], b_first[2], b_second[2];
@@ -736,11 +772,9 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
         char* const img2 = halo + HALO_BYTES;
         f32x4 acc[MT][2];
         int xaddr[MT], xaddr2[MT];
+        lane_pixels(xaddr, l15, lq);
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
-            xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
-            xaddr2[m] = m * 16 * HALO_STRIDE + lane2;
-        }
+        for (int m = 0; m < MT; m++) xaddr2[m] = xaddr[m] + base2;
         // halo_stage with all 14 rows of the source map in flight at once (one memory latency instead of two).
         // Named values, not an array (any statement the compiler cannot see through between an array's
         // writes and reads sends it through scratch), and a scheduler barrier that keeps the loads together
@@ -750,20 +784,20 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
             const int sx = tid >> 4, spc = tid & 15;
             const char* g = arena + (int64_t)t.src0 * slot_b + (sx < 14 ? sx : 0) * 256 + spc * 16;
             char* cell = ((pre2 || pre1) ? img2 : halo) +
-                         (sx < 14 ? (16 + sx + 1) * HALO_STRIDE + spc * 16 : 17 * HALO_STRIDE + 256 + (spc & 1) * 16);
+                         (sx < 14 ? HALO_ROW + (sx + 1) * HALO_STRIDE + spc * 16 : HALO_CENTER + 256 + (spc & 1) * 16);
 #define SOLO_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 #define SOLO_ASK(i) const uint4 st##i = *(const uint4*)(g + i * 14 * 256);
-#define SOLO_PUT(i) *(uint4*)(cell + i * 16 * HALO_STRIDE) = st##i;
+#define SOLO_PUT(i) *(uint4*)(cell + i * HALO_ROW) = st##i;
             SOLO_ROWS(SOLO_ASK)
             __builtin_amdgcn_sched_barrier(0);
             // the borders of both images, cleared under that latency (straight-line code: the last round repeats
             // writes of zeros instead of branching - across a branch the compiler sinks the loads to their uses)
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int idx = min(tid + 256 * k, 68 * 16 - 1), j = idx >> 4;
-            const int pos = j < 16 ? j : (j < 44 ? (((j - 16) >> 1) + 1) * 16 + ((j & 1) ? 15 : 0) : 240 + (j - 44));
-            *(uint4*)(halo + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
-            *(uint4*)(img2 + pos * HALO_STRIDE + (idx & 15) * 16) = make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < 4; k++) {
+            const int idx = min(tid + 256 * k, HALO_BORDER * 16 - 1);
+            const int at = halo_border_at(idx >> 4) + (idx & 15) * 16;
+            *(uint4*)(halo + at) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(img2 + at) = make_uint4(0, 0, 0, 0);
         }
             __builtin_amdgcn_sched_barrier(0);
             SOLO_ROWS(SOLO_PUT)
@@ -789,7 +823,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
             }
             wbase = (const char*)p.w_first + w33;
             load_wring(wr, wbase, wstep);
-            solo_epilogue<false, true>(halo, nullptr, acc, pre2 && relu, t.pre_mask >= 0 ? arena + (int64_t)t.pre_mask * slot_b : nullptr,
+            solo_epilogue<false, true>(halo, nullptr, xaddr, acc, pre2 && relu, t.pre_mask >= 0 ? arena + (int64_t)t.pre_mask * slot_b : nullptr,
                                        arena + (int64_t)t.res * slot_b, tid);
             s = 0;
         }
@@ -799,14 +833,14 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
         wbase = (const char*)p.w_second + w33;
         load_wring(wr, wbase, wstep);
         // (every wave is past the 1x1 pass's reads of the second image: the barrier of that pass's epilogue)
-        solo_epilogue<false, true>(img2, nullptr, acc, relu, t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
+        solo_epilogue<false, true>(img2, nullptr, xaddr, acc, relu, t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
         s = 0;
         STAMP(4);
         conv_kloop<9, true>(halo, xaddr2, wbase, wstep, 36, s, wr, acc, b_second, false);
         STAMP(5);
         // the result goes where the input is: each wave reads its own cells of it first, nobody else reads it
-        if (t.res >= 0) solo_epilogue<true, false>(halo, halo, acc, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
-        else solo_epilogue<false, false>(halo, nullptr, acc, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
+        if (t.res >= 0) solo_epilogue<true, false>(halo, halo, xaddr, acc, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
+        else solo_epilogue<false, false>(halo, nullptr, xaddr, acc, relu, t.mask0 >= 0 ? arena + (int64_t)t.mask0 * slot_b : nullptr, arena + (int64_t)t.dst0 * slot_b, tid);
         STAMP(6);
 #undef STAMP
         return;
@@ -846,8 +880,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
     halo_zero_border(halo, tid);
     f32x4 acc[MT][2];
     int xaddr[MT];
-#pragma unroll
-    for (int m = 0; m < MT; m++) xaddr[m] = (m * 16 + l15) * HALO_STRIDE + lq * 16;
+    lane_pixels(xaddr, l15, lq);
 
     halo_stage(halo, arena + (int64_t)t.src0 * slot_b, 256, tid, false);
     __syncthreads();
@@ -872,7 +905,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
         }
         wbase = (const char*)p.w_first + w33;
         load_wring(wr, wbase, wstep);
-        acc_to_image(halo, acc, pre2 && relu,
+        acc_to_image(halo, xaddr, acc, pre2 && relu,
                      t.pre_mask >= 0 ? arena + (int64_t)t.pre_mask * slot_b : nullptr,
                      arena + (int64_t)t.res * slot_b, tid);
         s = 0;
@@ -887,7 +920,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
     load_wring(wr, wbase, wstep);
     f32x4 bsecond[2];
     lane_bias(bsecond, has_bias ? p.bias_second + (int64_t)t.wgroup * 128 : nullptr, wave, lq);
-    acc_to_image(halo, acc, relu,
+    acc_to_image(halo, xaddr, acc, relu,
                  t.mask1 >= 0 ? arena + (int64_t)t.mask1 * slot_b : nullptr, arena + (int64_t)t.dst1 * slot_b, tid);
     s = 0;
     STAMP(4);
