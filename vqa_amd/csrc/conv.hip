@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiles_kernel(vqa_conv_params p) {
 //   4 rows x 2 pixel blocks x 4 pieces of a 32-lane read land on 64 different banks.
 //   one workgroup barrier per chunk: the producers hand over image c & 1 and then fill the other one, which
 //   the consumers left before they came to that barrier.
-// LDS: two images + four strips = 162 304 bytes, one workgroup of 8 waves per CU.  Same fragments, same K
+// LDS: two images + four strips = 163 456 bytes, one workgroup of 8 waves per CU.  Same fragments, same K
 // order, same rounding as vqa_nchw_to_nhwc + vqa_conv_tiles: the same bits.
 // ---------------------------------------------------------------------------------------------
 #define STRIP_STRIDE 320
