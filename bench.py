@@ -195,8 +195,6 @@ def main():
     net.to(dev).train()
     if os.environ.get('VQA_WGRAD_CHUNK'):
         net.wgrad_chunk = int(os.environ['VQA_WGRAD_CHUNK'])
-    if os.environ.get('VQA_STEM_PIECES'):          # diagnostics: pieces the input layout pass and the first convolution run in
-        net.stem_pieces = int(os.environ['VQA_STEM_PIECES'])
     step_net = net
     if world > 1 or force_dp:
         from vqa_amd.dp import DataParallelExecutor
