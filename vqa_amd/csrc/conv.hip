@@ -850,6 +850,12 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void resblock_tiles_kernel(vqa_r
     if (RANGE && tile_i >= tile_end) return;
     do {
     const vqa_resblock_tile t = p.tiles[tile_i];
+    // (with several tiles per workgroup everything derived from the thread's index would be computed once, in front
+    // of the loop, and held in registers across the whole tile body - 43 spilled registers; made opaque per
+    // tile it is recomputed, a few instructions)
+    int tid = threadIdx.x;
+    if (RANGE) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     // diagnostics: shader-clock timestamps of the phase boundaries of every tile
     unsigned long long* stamps = p.phase_stamps ? p.phase_stamps + (int64_t)blockIdx.x * 8 : nullptr;
 #define STAMP(i) if (stamps && tid == 0) stamps[i] = __builtin_readcyclecounter()
