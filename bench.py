@@ -263,9 +263,10 @@ def main():
         step(i)
     barrier()
     # The roofline figure needs the dominant kernel's launches timed with HIP events inside the
-    # timed region.  An event pair around a launch keeps it from overlapping its neighbours and
-    # costs about 5 us, so the launches of every tenth timed step are sampled, and only that
-    # kind; the other kinds are timed in a few extra steps after the timed region.
+    # timed region.  An event pair keeps what it brackets from overlapping its neighbours and
+    # costs about 5 us: the library brackets a tree pass's run of level launches with one pair
+    # (four pairs per step), every fifth timed step is sampled, and only that kind; the other
+    # kinds are timed in a few extra steps after the timed region.
     dominant = 'resblock' if a.module_dim == 128 else 'conv3x3'
     prof_on = os.environ.get('VQA_BENCH_NO_KERNEL_TIMING') is None
     sampled_steps = 0
@@ -275,8 +276,8 @@ def main():
     marks = []
     for i in range(a.steps):
         if prof_on:
-            ops.prof_enable([dominant] if i % 10 == 0 else False)
-            sampled_steps += i % 10 == 0
+            ops.prof_enable([dominant] if i % 5 == 0 else False)
+            sampled_steps += i % 5 == 0
         loss = step(a.warmup + i)
         marks.append(time.perf_counter())
         if os.environ.get('VQA_BENCH_VERBOSE') == '2':

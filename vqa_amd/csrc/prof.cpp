@@ -8,12 +8,15 @@
 #include <vector>
 
 namespace {
-struct Rec { int kind; double flops, bytes; hipEvent_t a, b; };
+struct Rec { int kind; double flops, bytes; hipEvent_t a, b; int launches; };
 std::mutex g_mu;
 unsigned g_mask = 0;   // bit k: launches of kind k are timed
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 Rec g_open;
+Rec g_run;               // the open run (kind < 0: none)
+bool g_run_open = false;
+bool g_nested = false;   // the launch being recorded belongs to the open run
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -27,14 +30,37 @@ bool vqa_prof_on(int kind) { return (g_mask >> kind) & 1u; }
 
 void vqa_prof_begin(int kind, double flops, double bytes, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_open = Rec{kind, flops, bytes, get_event(), get_event()};
+    g_nested = g_run_open && g_run.kind == kind;
+    if (g_nested) {
+        g_run.flops += flops; g_run.bytes += bytes; g_run.launches++;
+        return;
+    }
+    g_open = Rec{kind, flops, bytes, get_event(), get_event(), 1};
     (void)hipEventRecord(g_open.a, s);
 }
 
 void vqa_prof_end(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_nested) { g_nested = false; return; }
     (void)hipEventRecord(g_open.b, s);
     g_recs.push_back(g_open);
+}
+
+void vqa_prof_run_begin(int kind, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_run_open) return;          // one run at a time: an inner one is part of the outer
+    g_run = Rec{kind, 0.0, 0.0, get_event(), get_event(), 0};
+    g_run_open = true;
+    (void)hipEventRecord(g_run.a, s);
+}
+
+void vqa_prof_run_end(int kind, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_run_open || g_run.kind != kind) return;
+    (void)hipEventRecord(g_run.b, s);
+    g_run_open = false;
+    if (g_run.launches > 0) g_recs.push_back(g_run);
+    else { g_pool.push_back(g_run.a); g_pool.push_back(g_run.b); }
 }
 
 extern "C" int vqa_prof_enable(int32_t kind_mask) {
@@ -53,7 +79,7 @@ extern "C" int vqa_prof_collect(double* out, int32_t kinds) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            out[r.kind * 4 + 0] += 1.0;
+            out[r.kind * 4 + 0] += (double)r.launches;
             out[r.kind * 4 + 1] += ms;
             out[r.kind * 4 + 2] += r.flops;
             out[r.kind * 4 + 3] += r.bytes;

@@ -10,6 +10,22 @@ bool vqa_prof_on(int kind);
 void vqa_prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void vqa_prof_end(hipStream_t s);
 
+// A run of back-to-back launches of one kind (the levels of a tree pass) under ONE pair of events: while a run
+// is open, vqa_prof_begin / vqa_prof_end of that kind only add their launch's work to it.  An event pair per
+// launch keeps a launch from overlapping its neighbours and costs about 5 us; a pair per run costs that once,
+// and the run's time per launch includes what a kernel boundary costs.
+void vqa_prof_run_begin(int kind, hipStream_t s);
+void vqa_prof_run_end(int kind, hipStream_t s);
+
+struct VqaProfRun {
+    hipStream_t s;
+    int kind;
+    bool on;
+    VqaProfRun(int k, hipStream_t st) : s(st), kind(k), on(vqa_prof_on(k)) { if (on) vqa_prof_run_begin(kind, s); }
+    void end() { if (on) { vqa_prof_run_end(kind, s); on = false; } }
+    ~VqaProfRun() { end(); }
+};
+
 struct VqaProfScope {
     hipStream_t s;
     bool on;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "plan.h"
+#include "prof.h"
 
 namespace {
 
@@ -42,6 +43,9 @@ extern "C" int vqa_tree_forward(const vqa_plan* pl, const vqa_tree_ctx* c, void*
         vqa_set_error("vqa_tree_forward: the plan was built without the tile lists of this path");
         return VQA_EINVAL;
     }
+    // (timing, when it is on: the levels' launches follow each other with nothing between them - one pair of
+    // events around the run, not one per launch)
+    VqaProfRun prof_run(VQA_K_RESBLOCK, (hipStream_t)stream);
     for (int L = (c->flags & VQA_TREE_SKIP_LEVEL0) ? 1 : 0; L < pl->num_levels; L++) {
         const PlanLevel& lv = pl->levels[L];
         int rc;
@@ -113,9 +117,11 @@ extern "C" int vqa_tree_backward(const vqa_plan* pl, const vqa_tree_ctx* c, void
     }
     int rc;
     const bool f32 = (c->flags & VQA_TREE_F32) != 0;
+    VqaProfRun prof_run(VQA_K_RESBLOCK, (hipStream_t)stream);      // levels n - 1 .. 1: back to back
     for (int L = pl->num_levels - 1; L >= 0; L--) {
         const PlanLevel& lv = pl->levels[L];
         if (L == 0) {
+            prof_run.end();
             const int32_t* bl = c->blob;
             if (fused && pl->sec_cnt[VQA_SEC_SCENE_DPROJ_TILES] > 0) {
                 // binary nodes' dP -> the dZ of their inputs that are scene nodes (every other input
