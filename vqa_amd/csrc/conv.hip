@@ -179,6 +179,8 @@ __device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[M
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     const int pc = tid & 15;            // this thread's 16-byte column of every row: channels 8*pc..8*pc+7
     float* stg = (float*)halo;          // [112 pixels][132 floats]: 528-byte rows keep the writes conflict-free
+    // ReLU without a select per value: a signed 16-bit maximum with 0, or with the most negative value (no change)
+    const uint32_t floor_pk = relu ? 0u : 0x80008000u;
     // (a generic lambda called with a constant: a run-time `half` would select between accumulator
     // registers with one v_cndmask per value)
     auto do_half = [&](auto half_tag) {
@@ -217,8 +219,7 @@ __device__ __forceinline__ void conv_epilogue_t(char* halo, const f32x4 (&acc)[M
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (RES) o[j] += unpack_pk_bf16(r[j]);
-                    w[j] = cvt_pk_bf16(o[j]);
-                    if (relu) w[j] = relu_pk_bf16(w[j]);
+                    w[j] = max_pk_i16(cvt_pk_bf16(o[j]), floor_pk);
                     if (MASK) w[j] = mask_pk_bf16(w[j], k[j]);
                 }
                 *(uint4*)(dptr + g0 + (int64_t)i * 16 * pix_stride * 2) = make_uint4(w[0], w[1], w[2], w[3]);
