@@ -549,7 +549,10 @@ class ModuleNet(_WeightPacking, _Fp32Path, nn.Module):
                             (_lib.PLAN_SKIP_SEPARATE if fused else _lib.PLAN_SKIP_FUSED) |
                             (_lib.PLAN_BALANCE if self.balance_levels and need_grad else 0) | _lib.PLAN_DEFER_BACKWARD,
                             image_index=image_index, num_images=M if image_index is not None else None,
-                            blob_store=host)
+                            # (a plan that outlives the call - keep_state - keeps its tile lists in memory of
+                            # its own: the pinned buffer belongs to the workspace set and is written again
+                            # two calls later)
+                            blob_store=None if self.keep_state else host)
                 st['plan'] = plan
                 info = plan.info
                 nb, bound = info.blob_words, info.blob_words_bound
